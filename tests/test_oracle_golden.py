@@ -1,0 +1,102 @@
+"""Pin the CPU oracle (oracle/crop2seg_oracle.py) against outputs of the imported reference
+(tests/golden/*.npz, written by oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names
+from oracle import crop2seg_oracle as O
+
+# structurally-zero gradients: softmax shift invariance / bias followed by BatchNorm
+def _abs_only(name, training):
+    if name.endswith("attention_head.fc1_k.bias"):
+        return True
+    if not training:
+        return False
+    if name.startswith("up_blocks") and name.endswith(".0.bias"):
+        return True
+    if name.startswith("out_conv") and name.endswith(".bias") and name.split(".")[-2] in ("0", "3"):
+        return True
+    return name in ("temporal_encoder.mlp.0.bias", "temporal_encoder.inconv.bias", "temporal_encoder.in_norm.bias")
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_forward(goldens, name):
+    g = goldens(name)
+    bn = O.BNState()
+    with torch.no_grad():
+        kw = g.dropout_kwargs()
+        if g.cfg.model == "wtae":
+            kw.pop("mlp_keep", None)
+        logits, att = O.forward(g.sd, g.x, g.dates, g.cfg, training=g.training, bn=bn, **kw)
+        loss = O.cross_entropy(logits, g.y, 15)
+    ref_logits = torch.from_numpy(g.z["logits"])
+    ref_att = torch.from_numpy(g.z["att"])
+    scale = ref_logits.abs().max()
+    # train mode under weight_init-style BN gains is ill-conditioned: the fp32 reference differs from
+    # ITSELF by 1e-4 between 1 and 8 CPU threads
+    tol = 5e-4 if (g.training and g.meta["flavour"] == "wi") else 2e-5
+    assert (logits - ref_logits).abs().max() <= tol * scale, (logits - ref_logits).abs().max() / scale
+    assert (att - ref_att).abs().max() <= 2e-6
+    assert abs(float(loss) - float(g.z["loss"])) <= 1e-5 * abs(float(g.z["loss"]))
+    if not g.training:
+        # argmax class map bit-exact (ties -> lowest index, like torch.argmax)
+        assert torch.equal(logits.argmax(1), ref_logits.argmax(1))
+    else:
+        for k in g.z.files:
+            if k.startswith("bn/"):
+                ref = torch.from_numpy(g.z[k])
+                got = bn.updates[k[3:]]
+                assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max())), k
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_backward(goldens, name):
+    g = goldens(name)
+    kw = g.dropout_kwargs()
+    if g.cfg.model == "wtae":
+        kw.pop("mlp_keep", None)
+    _, loss, grads, _ = O.loss_and_grads(g.sd, g.x, g.dates, g.y, g.cfg, g.training, **kw)
+    names = g.grad_names()
+    assert set(names) == set(grads.keys())
+    gmax = max(float(g.z[f"grad/{n}/norm"]) for n in names)
+    # train-mode gradients under weight_init-style weights: the fp32 reference differs from itself by
+    # 1.5-3.6e-2 between thread counts; everywhere else 2e-3 is generous.
+    rtol = 5e-2 if (g.training and g.meta["flavour"] == "wi") else 2e-3
+    for n in names:
+        err, scale, ref_norm, got_norm = g.check_grad(n, grads[n], 0)
+        if _abs_only(n, g.training) or ref_norm < 1e-7 * gmax:
+            assert err <= (1e-4 if rtol > 1e-2 else 1e-5) * gmax, (n, err, gmax)
+        else:
+            # same torch CPU ops in the same order -> agreement far below the 1e-3 protocol bar
+            assert err <= rtol * scale + 1e-7 * gmax, (n, err / max(scale, 1e-30))
+            assert abs(got_norm - ref_norm) <= rtol * ref_norm + 1e-7 * gmax, n
+
+
+def test_oracle_fp64_runs(goldens):
+    """The functional oracle runs in float64 (the reference cannot: temp_shared_block.py:25)."""
+    g = goldens("utae_eval_pad_wi")
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in g.sd.items()}
+    with torch.no_grad():
+        l64, _ = O.forward(sd64, g.x.double(), g.dates, g.cfg)
+    ref = torch.from_numpy(g.z["logits"]).double()
+    assert l64.dtype == torch.float64
+    assert (l64 - ref).abs().max() <= 1e-4 * ref.abs().max()
+
+
+def test_padded_frames_semantics():
+    """A padded frame leaves the encoder as exactly pad_value and gets exactly zero attention
+    (SURVEY Appendix N.5)."""
+    g = torch.Generator().manual_seed(0)
+    cfg = O.BackboneConfig()
+    x = torch.randn(1, 3, 10, 16, 16, generator=g)
+    x[0, 2] = 0
+    from oracle import seeded
+    ks = [("in_conv.conv.conv.0.weight", (64, 10, 3, 3)), ("in_conv.conv.conv.0.bias", (64,)),
+          ("in_conv.conv.conv.1.weight", (64,)), ("in_conv.conv.conv.1.bias", (64,)),
+          ("in_conv.conv.conv.3.weight", (64, 64, 3, 3)), ("in_conv.conv.conv.3.bias", (64,)),
+          ("in_conv.conv.conv.4.weight", (64,)), ("in_conv.conv.conv.4.bias", (64,))]
+    sd = seeded.make_state(ks, 3, "tame")
+    out = O.conv_block(x, sd, "in_conv", 2, "group", cfg, False, None, 0.0)
+    assert torch.equal(out[0, 2], torch.zeros_like(out[0, 2]))
+    assert out[0, :2].abs().sum() > 0
