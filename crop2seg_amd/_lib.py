@@ -1,0 +1,117 @@
+"""ctypes binding of libc2s_hip.so (the C ABI declared in include/c2s_hip.h).
+
+The product path has NO CPU fallback: if the library cannot be loaded, `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libc2s_hip.so")
+
+c_float_p = C.c_void_p   # device pointers are passed as integers (tensor.data_ptr())
+c_int_p = C.c_void_p
+
+PAD_ZEROS, PAD_REFLECT = 0, 1
+NORM_GROUP, NORM_BATCH = 0, 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "C0", "C1", "Hin", "Win", "Cout", "CoutP", "Hout", "Wout", "OutH", "OutW", "KH", "KW", "S",
+        "pad_y", "pad_x", "pad_mode", "osy", "osx", "ooy", "oox", "accumulate")]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "C0", "C1", "Hin", "Win", "Cout", "Hout", "Wout", "KH", "KW", "S", "pad_y", "pad_x", "pad_mode",
+        "nslices")]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("kind", C.c_int), ("groups", C.c_int),
+                ("training", C.c_int), ("eps", C.c_float), ("momentum", C.c_float)]
+
+
+class LtaeDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("n_head", C.c_int),
+                ("d_model", C.c_int), ("eps", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
+                ("keep", C.c_void_p)]
+
+
+class AggDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "C", "H", "W", "n_head", "h", "w")]
+
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+SZ = C.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/c2s_hip.h
+SIGNATURES = {
+    "c2s_abi_version": (I, []),
+    "c2s_last_error": (C.c_char_p, []),
+    "c2s_device_cus": (I, []),
+    "c2s_pack_weights": (I, [P, P, I, I, I, I, L, L, C.POINTER(I), P]),
+    "c2s_conv_igemm": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "c2s_conv_reflect_dgrad_border": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "c2s_wgrad_workspace_floats": (SZ, [C.POINTER(WgradDesc)]),
+    "c2s_conv_wgrad": (I, [C.POINTER(WgradDesc), P, P, P, P, SZ, P, P]),
+    "c2s_wgrad_reduce": (I, [C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, P]),
+    "c2s_dwconv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "c2s_dwconv_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "c2s_dwconv_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "c2s_norm_workspace_floats": (SZ, [C.POINTER(NormDesc)]),
+    "c2s_norm_stats": (I, [C.POINTER(NormDesc), P, P, P, P, P, P, P, P, SZ, P, P]),
+    "c2s_norm_apply": (I, [C.POINTER(NormDesc), P, P, P, P, I, P, F, P]),
+    "c2s_norm_bwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, I, P, P, P, P, P, SZ, P, P]),
+    "c2s_frame_flags": (I, [P, P, I, L, F, P]),
+    "c2s_ltae_attn_fwd": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P]),
+    "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
+    "c2s_ltae_attn_bwd": (I, [C.POINTER(LtaeDesc)] + [P] * 22 + [SZ, P]),
+    "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P]),
+    "c2s_pixel_gn_fwd": (I, [P, P, P, P, P, I, I, I, I, F, P]),
+    "c2s_pixel_gn_bwd_workspace_floats": (SZ, [I, I, I]),
+    "c2s_pixel_gn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "c2s_temporal_aggregate_fwd": (I, [C.POINTER(AggDesc), P, P, P, P, P]),
+    "c2s_temporal_aggregate_bwd_workspace_floats": (SZ, [C.POINTER(AggDesc)]),
+    "c2s_temporal_aggregate_bwd": (I, [C.POINTER(AggDesc), P, P, P, P, P, I, P, P, SZ, P]),
+    "c2s_cross_entropy_workspace_floats": (SZ, [I, I]),
+    "c2s_cross_entropy": (I, [P, P, P, P, P, I, I, I, P, SZ, P]),
+    "c2s_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "c2s_fill": (I, [P, L, F, P]),
+    "c2s_add_inplace": (I, [P, P, L, P]),
+}
+
+_LIB: Optional[C.CDLL] = None
+
+
+class C2SError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libc2s_hip.so (once).  Raises if it is missing: there is no fallback path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise C2SError(
+                f"{LIB_PATH} not found: build it with `python -m crop2seg_amd.build` "
+                "(or __graft_entry__.build()); crop2seg_amd has no CPU/PyTorch fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().c2s_last_error().decode(errors="replace")
+        raise C2SError(f"{what} failed (code {rc}): {msg}")

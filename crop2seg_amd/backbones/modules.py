@@ -1,0 +1,383 @@
+"""Drop-in model classes: UTAE, TimeUNet_v1, WTAE with the reference's constructor signature, forward()
+contract and state_dict layout, executing on the HIP engine.
+
+The submodules are *parameter holders* built from the same torch layer classes at the same module paths as
+the reference (so `model.apply(weight_init)`, `load_state_dict` of a reference checkpoint, `.to()`,
+`.train()/.eval()` and optimisers behave identically; reference src/learning/weight_init.py:13-46 dispatches on
+isinstance).  Their own forward() is never used: the top-level model runs
+crop2seg_amd.backbones.functional.* through libc2s_hip.so.  There is no PyTorch/CPU fallback: calling a model on
+a non-HIP tensor or without the library raises.
+
+Reference classes mirrored: src/backbones/utae.py:14, timeunet.py:10, wtae.py:15, conv.py:11,29,168,238,362,
+tae.py:349,507,738, temporal_aggregator.py:6, positional_encoding.py:7.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from . import functional as Fn
+
+Tensor = torch.Tensor
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter-holder blocks (module paths == reference)
+# ------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} is a parameter holder; run the enclosing backbone instead")
+
+
+class DepthwiseSeparableConv2D(_Holder):
+    """reference conv.py:11-26 (both convolutions bias-free)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, padding_mode="zeros", stride=1, bias=False):
+        super().__init__()
+        self.depthwise = nn.Conv2d(in_channels, in_channels, kernel_size, padding=padding, padding_mode=padding_mode,
+                                   stride=stride, groups=in_channels, bias=bias)
+        self.pointwise = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=bias)
+
+
+class ConvLayer(_Holder):
+    """reference conv.py:29-96: Sequential [conv, norm, ReLU] * (len(nkernels)-1)."""
+
+    def __init__(self, nkernels, norm="batch", k=3, s=1, p=1, n_groups=4, last_relu=True, padding_mode="reflect",
+                 conv_type="2d", add_squeeze=False):
+        super().__init__()
+        if add_squeeze or not last_relu or n_groups != 4:
+            raise NotImplementedError("crop2seg_amd builds the default ConvLayer configuration only")
+        layers: List[nn.Module] = []
+        for i in range(len(nkernels) - 1):
+            if conv_type == "depthwise_separable":
+                layers.append(DepthwiseSeparableConv2D(nkernels[i], nkernels[i + 1], kernel_size=k, padding=p, stride=s,
+                                                       padding_mode=padding_mode))
+            else:
+                layers.append(nn.Conv2d(nkernels[i], nkernels[i + 1], kernel_size=k, padding=p, stride=s,
+                                        padding_mode=padding_mode))
+            if norm == "batch":
+                layers.append(nn.BatchNorm2d(nkernels[i + 1]))
+            elif norm == "group":
+                layers.append(nn.GroupNorm(num_channels=nkernels[i + 1], num_groups=n_groups))
+            else:
+                raise NotImplementedError(f"norm={norm!r}: crop2seg_amd builds 'group' and 'batch'")
+            layers.append(nn.ReLU())
+        self.conv = nn.Sequential(*layers)
+
+
+class ConvBlock(_Holder):
+    """reference conv.py:168-200."""
+
+    def __init__(self, nkernels, pad_value=None, norm="batch", last_relu=True, padding_mode="reflect", conv_type="2d",
+                 add_squeeze=False):
+        super().__init__()
+        self.pad_value = pad_value
+        self.conv = ConvLayer(nkernels, norm=norm, last_relu=last_relu, padding_mode=padding_mode, conv_type=conv_type,
+                              add_squeeze=add_squeeze)
+
+
+class DownConvBlock(_Holder):
+    """reference conv.py:238-296."""
+
+    def __init__(self, d_in, d_out, k, s, p, pad_value=None, norm="batch", padding_mode="reflect", conv_type="2d",
+                 add_squeeze=False):
+        super().__init__()
+        if add_squeeze:
+            raise NotImplementedError("squeeze-and-excitation is not built (reference flag --add_squeeze, default off)")
+        self.pad_value = pad_value
+        self.down = ConvLayer([d_in, d_in], norm=norm, k=k, s=s, p=p, padding_mode=padding_mode, conv_type=conv_type)
+        self.conv1 = ConvLayer([d_in, d_out], norm=norm, padding_mode=padding_mode, conv_type=conv_type)
+        self.conv2 = ConvLayer([d_out, d_out], norm=norm, padding_mode=padding_mode, conv_type=conv_type)
+
+
+class UpConvBlock(_Holder):
+    """reference conv.py:362-413."""
+
+    def __init__(self, d_in, d_out, k, s, p, norm="batch", d_skip=None, padding_mode="reflect", conv_type="2d",
+                 add_squeeze=False):
+        super().__init__()
+        if add_squeeze:
+            raise NotImplementedError("squeeze-and-excitation is not built")
+        d = d_out if d_skip is None else d_skip
+        self.skip_conv = nn.Sequential(nn.Conv2d(d, d, kernel_size=1), nn.BatchNorm2d(d), nn.ReLU())
+        self.up = nn.Sequential(nn.ConvTranspose2d(d_in, d_out, kernel_size=k, stride=s, padding=p),
+                                nn.BatchNorm2d(d_out), nn.ReLU())
+        self.conv1 = ConvLayer([d_out + d, d_out], norm=norm, padding_mode=padding_mode, conv_type=conv_type)
+        self.conv2 = ConvLayer([d_out, d_out], norm=norm, padding_mode=padding_mode, conv_type=conv_type)
+
+
+class LightweightMultiHeadAttention(_Holder):
+    """reference tae.py:738-758: learnable master query Q [n_head, n, d_k] and the key projection fc1_k."""
+
+    def __init__(self, n_head, d_k, d_in, n=1):
+        super().__init__()
+        self.n_head, self.d_k, self.d_in, self.n = n_head, d_k, d_in, n
+        self.Q = nn.Parameter(torch.zeros((n_head, n, d_k))).requires_grad_(True)
+        nn.init.normal_(self.Q, mean=0, std=np.sqrt(2.0 / d_k))
+        self.fc1_k = nn.Linear(d_in, n_head * d_k)
+        nn.init.normal_(self.fc1_k.weight, mean=0, std=np.sqrt(2.0 / d_k))
+
+
+class PositionalEncoder(_Holder):
+    """reference positional_encoding.py:7-43 (no parameters unless add_linear; the table is computed by
+    crop2seg_amd.engine.positional_table)."""
+
+    def __init__(self, d_model, T=1000, repeat=None, offset=0, add_linear=False):
+        super().__init__()
+        if add_linear or offset != 0:
+            raise NotImplementedError("PositionalEncoder(add_linear/offset) is not built")
+        self.d, self.T, self.repeat = d_model, T, repeat
+
+
+class LTAE(_Holder):
+    """reference tae.py:349-449."""
+
+    def __init__(self, in_channels=128, n_head=16, d_k=4, mlp=[256, 128], dropout=0.2, d_model=256, T=1000,
+                 positional_encoding=True, use_abs_rel_enc=False, use_doy=False, num_queries=1, add_linear=False,
+                 *args, **kwargs):
+        super().__init__()
+        if use_abs_rel_enc or use_doy or add_linear or num_queries != 1 or not positional_encoding or d_model is None:
+            raise NotImplementedError("crop2seg_amd builds the default L-TAE (relative sinusoidal dates, one query)")
+        self.in_channels, self.n_head, self.d_k, self.d_model, self.T = in_channels, n_head, d_k, d_model, T
+        self.dropout_p = dropout
+        mlp = copy.deepcopy(mlp)
+        assert mlp[0] == d_model and len(mlp) == 2
+        self.inconv = nn.Conv1d(in_channels, d_model, 1)
+        self.positional_encoder = PositionalEncoder(d_model // n_head, T=T, repeat=n_head)
+        self.attention_head = LightweightMultiHeadAttention(n_head=n_head, d_k=d_k, d_in=d_model, n=num_queries)
+        self.in_norm = nn.GroupNorm(num_groups=n_head, num_channels=in_channels)
+        self.out_norm = nn.GroupNorm(num_groups=n_head, num_channels=mlp[-1])
+        # indices 0 and 2 carry parameters (the reference has einops Rearrange at 1 and 3: tae.py:442-449)
+        self.mlp = nn.Sequential(nn.Linear(mlp[0], mlp[1]), nn.Identity(), nn.BatchNorm1d(mlp[1]), nn.Identity(),
+                                 nn.ReLU(), nn.Dropout(dropout))
+
+
+class LTAE4WTAE(_Holder):
+    """reference tae.py:507-587: attention masks only (no mlp / out_norm parameters)."""
+
+    def __init__(self, in_channels=128, n_head=16, d_k=4, d_model=256, positional_encoding=True, use_abs_rel_enc=False,
+                 num_queries=1, use_doy=False, add_linear=False, *args, **kwargs):
+        super().__init__()
+        if use_abs_rel_enc or use_doy or add_linear or num_queries != 1 or not positional_encoding or d_model is None:
+            raise NotImplementedError("crop2seg_amd builds the default L-TAE (relative sinusoidal dates, one query)")
+        self.in_channels, self.n_head, self.d_k, self.d_model = in_channels, n_head, d_k, d_model
+        self.inconv = nn.Conv1d(in_channels, d_model, 1)
+        self.positional_encoder = PositionalEncoder(d_model // n_head, repeat=n_head)
+        self.attention_head = LightweightMultiHeadAttention(n_head=n_head, d_k=d_k, d_in=d_model, n=num_queries)
+        self.in_norm = nn.GroupNorm(num_groups=n_head, num_channels=in_channels)
+
+
+class TemporalAggregator(_Holder):
+    """reference temporal_aggregator.py:6-12 (mode att_group is built)."""
+
+    def __init__(self, mode="mean"):
+        super().__init__()
+        if mode != "att_group":
+            raise NotImplementedError(f"agg_mode={mode!r}: crop2seg_amd builds 'att_group'")
+        self.mode = mode
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd bridge: one Function for the whole backbone (explicit tape inside)
+# ------------------------------------------------------------------------------------------------
+class _BackboneFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, dates, drop, names, *params):
+        p = dict(zip(names, params))
+        grads = {n: torch.empty_like(t) for n, t in p.items()}
+        tape = E.Tape()
+        ectx = E.Ctx(p, dict(module.named_buffers()), grads, module._workspace(x.device), module.training, tape)
+        with torch.no_grad():
+            logits, att = Fn.FORWARDS[module.spec.model](ectx, module.spec, x, dates, drop)
+        ctx.tape, ctx.ectx, ctx.names, ctx.logits = tape, ectx, names, logits
+        ctx.mark_non_differentiable(att)
+        return logits, att
+
+    @staticmethod
+    def backward(ctx, g_logits, _g_att):
+        tape, ectx = ctx.tape, ctx.ectx
+        with torch.no_grad():
+            tape.grads[ctx.logits.data_ptr()] = g_logits.contiguous().clone()
+            tape.backward()
+            out = []
+            for n in ctx.names:
+                g = ectx.g[n]
+                if n not in ectx._gwritten:
+                    g.zero_()
+                out.append(g)
+        return (None, None, None, None, None, *out)
+
+
+class _Backbone(nn.Module):
+    spec: Fn.BackboneSpec
+
+    def _workspace(self, device) -> E.Workspace:
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.device != device:
+            ws = E.Workspace(device)
+            object.__setattr__(self, "_ws", ws)
+        return ws
+
+    def _check_inputs(self, input: Tensor, batch_positions: Optional[Tensor]):
+        if batch_positions is None:
+            raise ValueError("batch_positions (acquisition dates [B,T]) is required by the L-TAE positional encoding")
+        if not input.is_cuda:
+            raise RuntimeError("crop2seg_amd runs on MI355X only (no CPU fallback): move the model and inputs to 'cuda'")
+        if input.dim() != 5 or input.dtype != torch.float32:
+            raise ValueError("input must be float32 [B,T,C,H,W]")
+        H, W = input.shape[-2:]
+        if H % 8 or W % 8 or H < 16 or W < 16:
+            raise ValueError("H and W must be multiples of 8 and >= 16")
+        if batch_positions.dim() != 2:
+            raise NotImplementedError("batch_positions [B,T,2] (use_abs_rel_enc) is not built")
+
+    def forward(self, input: Tensor, batch_positions: Optional[Tensor] = None, return_att: bool = False,
+                dropout_state: Optional[Fn.DropoutState] = None, *args, **kwargs):
+        self._check_inputs(input, batch_positions)
+        x = input.contiguous()
+        dates = batch_positions.contiguous()
+        drop = dropout_state
+        if drop is None:
+            drop = Fn.DropoutState()
+            if self.training:
+                seeds = torch.randint(0, 2 ** 62, (2,), device="cpu")   # host RNG (torch.manual_seed reproducible)
+                drop.attn_seed, drop.mlp_seed = int(seeds[0]), int(seeds[1])
+        named = [(n, p) for n, p in self.named_parameters()]
+        names = [n for n, _ in named]
+        params = [p for _, p in named]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            logits, att = _BackboneFunction.apply(self, x, dates, drop, names, *params)
+        else:
+            with torch.no_grad():
+                ectx = E.Ctx(dict(named), dict(self.named_buffers()), None, self._workspace(x.device), self.training, None)
+                logits, att = Fn.FORWARDS[self.spec.model](ectx, self.spec, x, dates, drop)
+        if self.encoder or self.return_maps:
+            raise NotImplementedError("encoder / return_maps outputs are not built")
+        if return_att:
+            return logits, att
+        return logits
+
+
+def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k, str_conv_s, str_conv_p,
+                 agg_mode, encoder_norm, n_head, d_model, d_k, encoder, return_maps, pad_value, padding_mode, conv_type,
+                 use_mbconv, add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss):
+    unsupported = dict(use_mbconv=use_mbconv, add_squeeze_excit=add_squeeze_excit, use_abs_rel_enc=use_abs_rel_enc,
+                       use_doy=use_doy, add_linear=add_linear, add_boundary_loss=add_boundary_loss,
+                       encoder=encoder, return_maps=return_maps)
+    bad = [k for k, v in unsupported.items() if v]
+    if bad or num_queries != 1 or conv_type != "2d" or agg_mode != "att_group":
+        raise NotImplementedError(
+            "crop2seg_amd builds the reference's default backbone configuration (train.py:32-47,153-166); "
+            f"off-default options are not built: {bad or dict(num_queries=num_queries, conv_type=conv_type, agg_mode=agg_mode)}")
+    if decoder_widths is None:
+        decoder_widths = encoder_widths
+    assert len(encoder_widths) == len(decoder_widths)
+    assert encoder_widths[-1] == decoder_widths[-1]
+    self.n_stages = len(encoder_widths)
+    self.return_maps = return_maps
+    self.encoder = encoder
+    self.encoder_widths = encoder_widths
+    self.decoder_widths = decoder_widths
+    self.enc_dim = decoder_widths[0]
+    self.stack_dim = sum(decoder_widths)
+    self.pad_value = pad_value
+    self.conv_type = conv_type
+    self.spec = Fn.BackboneSpec(model=model, input_dim=input_dim, encoder_widths=list(encoder_widths),
+                                decoder_widths=list(decoder_widths), out_conv=list(out_conv), str_conv_k=str_conv_k,
+                                str_conv_s=str_conv_s, str_conv_p=str_conv_p, agg_mode=agg_mode,
+                                encoder_norm=encoder_norm, n_head=n_head, d_model=d_model, d_k=d_k,
+                                pad_value=float(pad_value), padding_mode=padding_mode)
+    return decoder_widths
+
+
+def _enc_blocks(encoder_widths, k, s, p, pad_value, norm, padding_mode, conv_type="2d"):
+    return nn.ModuleList(
+        DownConvBlock(d_in=encoder_widths[i], d_out=encoder_widths[i + 1], k=k, s=s, p=p, pad_value=pad_value,
+                      norm=norm, padding_mode=padding_mode, conv_type=conv_type)
+        for i in range(len(encoder_widths) - 1))
+
+
+def _dec_blocks(encoder_widths, decoder_widths, k, s, p, padding_mode):
+    n = len(encoder_widths)
+    return nn.ModuleList(
+        UpConvBlock(d_in=decoder_widths[i], d_out=decoder_widths[i - 1], d_skip=encoder_widths[i - 1], k=k, s=s, p=p,
+                    norm="batch", padding_mode=padding_mode)
+        for i in range(n - 1, 0, -1))
+
+
+class UTAE(_Backbone):
+    """reference src/backbones/utae.py:14-252."""
+
+    def __init__(self, input_dim, encoder_widths=[64, 64, 64, 128], decoder_widths=[32, 32, 64, 128], out_conv=[32, 20],
+                 str_conv_k=4, str_conv_s=2, str_conv_p=1, agg_mode="att_group", encoder_norm="group", n_head=16,
+                 d_model=256, d_k=4, encoder=False, return_maps=False, pad_value=0, padding_mode="reflect",
+                 conv_type="2d", use_mbconv=False, add_squeeze_excit=False, use_abs_rel_enc=False, num_queries=1,
+                 use_doy=False, add_linear=False, add_boundary_loss=False, *args, **kwargs):
+        super().__init__()
+        decoder_widths = _common_init(self, "utae", input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k,
+                                      str_conv_s, str_conv_p, agg_mode, encoder_norm, n_head, d_model, d_k, encoder,
+                                      return_maps, pad_value, padding_mode, conv_type, use_mbconv, add_squeeze_excit,
+                                      use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss)
+        self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
+                                 norm=encoder_norm, padding_mode=padding_mode)
+        self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
+                                       padding_mode)
+        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
+        self.temporal_encoder = LTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
+        self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
+        self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
+
+
+class TimeUNet_v1(_Backbone):
+    """reference src/backbones/timeunet.py:10-210."""
+
+    def __init__(self, input_dim, encoder_widths=[64, 64, 64, 128], decoder_widths=[32, 32, 64, 128], out_conv=[32, 20],
+                 str_conv_k=4, str_conv_s=2, str_conv_p=1, encoder_norm="group", n_head=16, d_model=256, d_k=4,
+                 encoder=False, return_maps=False, pad_value=0, padding_mode="reflect", conv_type="2d",
+                 add_squeeze_excit=False, use_abs_rel_enc=False, num_queries=1, use_doy=False, add_linear=False,
+                 *args, **kwargs):
+        super().__init__()
+        kwargs.pop("agg_mode", None)
+        decoder_widths = _common_init(self, "timeunet", input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k,
+                                      str_conv_s, str_conv_p, "att_group", encoder_norm, n_head, d_model, d_k, encoder,
+                                      return_maps, pad_value, padding_mode, conv_type, kwargs.get("use_mbconv", False),
+                                      add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear,
+                                      kwargs.get("add_boundary_loss", False))
+        self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
+                                 norm=encoder_norm, padding_mode=padding_mode)
+        self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
+                                       padding_mode)
+        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
+        self.temporal_encoder = LTAE(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
+                                     mlp=[d_model, encoder_widths[0]])
+        self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
+
+
+class WTAE(_Backbone):
+    """reference src/backbones/wtae.py:15-279."""
+
+    def __init__(self, input_dim, encoder_widths=[64, 64, 64, 128], decoder_widths=[32, 32, 64, 128], out_conv=[32, 20],
+                 str_conv_k=4, str_conv_s=2, str_conv_p=1, agg_mode="att_group", encoder_norm="group", n_head=16,
+                 d_model=256, d_k=4, encoder=False, return_maps=False, pad_value=0, padding_mode="reflect",
+                 conv_type="2d", use_mbconv=False, add_squeeze_excit=False, use_abs_rel_enc=False, num_queries=1,
+                 use_doy=False, add_linear=False, add_boundary_loss=False, *args, **kwargs):
+        super().__init__()
+        decoder_widths = _common_init(self, "wtae", input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k,
+                                      str_conv_s, str_conv_p, agg_mode, encoder_norm, n_head, d_model, d_k, encoder,
+                                      return_maps, pad_value, padding_mode, conv_type, use_mbconv, add_squeeze_excit,
+                                      use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss)
+        self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
+                                 norm=encoder_norm, padding_mode=padding_mode)
+        self.spatial_reduction = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
+                                             padding_mode, conv_type="depthwise_separable")
+        self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
+                                       padding_mode)
+        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
+        self.temporal_encoder = LTAE4WTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
+        self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
+        self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)

@@ -1,0 +1,263 @@
+// Weight gradient of the convolutions as a split-K implicit GEMM on the exact-f32 MFMA.
+//
+//   slab[s][tap][cin][cout] = sum_{(n,oy,ox) in slice s} In[n][cin][gather(oy,ox,tap)] * Gout[n][cout][oy][ox]
+//
+// MFMA view: A[i = cin][k = position], B[k = position][j = cout]  ->  D[cin][cout] per tap.
+// Workgroup = 256 threads: one 32-channel cin block x one 64-channel cout block x all taps; wave w owns
+// cout fragment (w & 1) and the taps t with t % 2 == (w >> 1)  (<= 8 accumulators of 16 VGPRs).
+// The K dimension (N*Hout*Wout positions, up to millions) is split into `nslices` strided sets of
+// position tiles; each workgroup keeps its accumulators in registers over its whole slice and writes one
+// slab.  c2s_wgrad_reduce sums the slabs in a fixed order (bitwise reproducible, no float atomics) and
+// scatters into the torch weight layout.
+// LDS: input tile [32][plane | odd stride] and gout tile [64][TP+1]: lanes that differ in channel hit
+// different banks because both strides are odd.
+//
+// Reference call sites replaced: convolution_backward-weight of src/backbones/conv.py:70-80,263-271,
+// 378-390.
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    const float* src0;
+    const float* src1;
+    const float* gout;
+    float* slabs;
+    const int* valid;
+    int N, C0, C1, Hin, Win, Cout, Hout, Wout;
+    int pad_y, pad_x, pad_mode;
+    int nslices, ntiles, tiles_x, tiles_y, log2pc;
+    int CinP, CoutB;
+};
+
+constexpr int wg_cmax(int a, int b) { return a > b ? a : b; }
+template <int K, int S>
+struct WCfg {
+    static constexpr int TP = (S == 2) ? 64 : 128;     // positions per tile
+    static constexpr int NT = K * K;
+    static constexpr int TH = (NT + 1) / 2;            // taps per wave half
+    static constexpr int plane_for(int l2) { return (((TP >> l2) - 1) * S + K) * (((1 << l2) - 1) * S + K); }
+    static constexpr int MAXPLANE = wg_cmax(wg_cmax(plane_for(2), plane_for(3)), wg_cmax(plane_for(4), plane_for(5))) | 1;
+    static constexpr int MAXE = (32 * MAXPLANE + 255) / 256;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    using C = WCfg<K, S>;
+    constexpr int TP = C::TP, NT = C::NT, TH = C::TH, MAXE = C::MAXE;
+    extern __shared__ float lds[];
+
+    const int PC = 1 << p.log2pc, PR = TP >> p.log2pc;
+    const int rows = (PR - 1) * S + K, cols = (PC - 1) * S + K;
+    const int plane = rows * cols;
+    const int planeP = plane | 1;
+    float* Xl = lds;                   // [32][planeP]
+    float* Gl = lds + 32 * planeP;     // [64][TP+1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int ofrag = wave & 1, thalf = wave >> 1;
+    const int cb = blockIdx.y * 32, ob = blockIdx.z * 64;
+    const int slice = blockIdx.x;
+    const int Cin = p.C0 + p.C1;
+    const int HWin = p.Hin * p.Win, HWo = p.Hout * p.Wout;
+
+    // element decomposition of the staging loop (fixed for the whole kernel)
+    int epk[MAXE];
+    const int total = 32 * plane;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int e = tid + i * 256;
+        int pk = -1;
+        if (e < total) {
+            const int c = e / plane;
+            const int rem = e - c * plane;
+            const int r = rem / cols;
+            pk = (c << 20) | (r << 10) | (rem - r * cols);
+        }
+        epk[i] = pk;
+    }
+
+    f32x16 acc[TH];
+#pragma unroll
+    for (int i = 0; i < TH; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int tile = slice; tile < p.ntiles; tile += p.nslices) {
+        const int n = tile / (p.tiles_x * p.tiles_y);
+        const int trem = tile - n * (p.tiles_x * p.tiles_y);
+        const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+        if (p.valid != nullptr && p.valid[n] == 0) continue;
+        const int oy0 = tyi * PR, ox0 = txi * PC;
+        // ---- stage input tile
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HWin;
+        const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HWin : nullptr;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int pk = epk[i];
+            if (pk >= 0) {
+                const int c = pk >> 20, r = (pk >> 10) & 1023, cc = pk & 1023;
+                int gy = oy0 * S - p.pad_y + r, gx = ox0 * S - p.pad_x + cc;
+                bool ok;
+                if (p.pad_mode == C2S_PAD_REFLECT) {
+                    ok = gy >= -p.pad_y && gy < p.Hin + p.pad_y && gx >= -p.pad_x && gx < p.Win + p.pad_x;
+                    gy = reflect_idx(gy, p.Hin);
+                    gx = reflect_idx(gx, p.Win);
+                } else {
+                    ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                }
+                const int cg = cb + c;
+                float v = 0.f;
+                if (ok && cg < Cin) {
+                    const float* s = cg < p.C0 ? s0n + (size_t)cg * HWin : s1n + (size_t)(cg - p.C0) * HWin;
+                    v = s[gy * p.Win + gx];
+                }
+                Xl[c * planeP + r * cols + cc] = v;
+            }
+        }
+        // ---- stage gout tile [64][TP]
+        {
+            const float* gn = p.gout + (size_t)n * p.Cout * HWo;
+            for (int e = tid; e < 64 * TP; e += 256) {
+                const int o = e / TP, q = e % TP;
+                const int oy = oy0 + (q >> p.log2pc), ox = ox0 + (q & (PC - 1));
+                float v = 0.f;
+                if (ob + o < p.Cout && oy < p.Hout && ox < p.Wout) v = gn[(size_t)(ob + o) * HWo + oy * p.Wout + ox];
+                Gl[o * (TP + 1) + q] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over position pairs
+        for (int kk = 0; kk < TP / 2; ++kk) {
+            const int q = 2 * kk + lk;
+            const int qy = q >> p.log2pc, qx = q & (PC - 1);
+            const float b = Gl[(ofrag * 32 + li) * (TP + 1) + q];
+            const int abase = li * planeP + (qy * S) * cols + qx * S;
+#pragma unroll
+            for (int i = 0; i < TH; ++i) {
+                const int t = 2 * i + thalf;
+                if (t < NT) {
+                    const float a = Xl[abase + (t / K) * cols + (t % K)];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write slab [slice][tap][CinP][CoutB]
+#pragma unroll
+    for (int i = 0; i < TH; ++i) {
+        const int t = 2 * i + thalf;
+        if (t < NT) {
+            float* sl = p.slabs + (((size_t)slice * NT + t) * p.CinP + cb) * p.CoutB + ob + ofrag * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                sl[(size_t)ci * p.CoutB] = acc[i][r];
+            }
+        }
+    }
+}
+
+struct TapTable {
+    int off[16];
+};
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst, int nslices, int NT,
+                                    int Cin, int Cout, int CinP, int CoutB, long so, long sc, TapTable tt,
+                                    int accumulate) {
+    const long total = (long)NT * Cin * Cout;
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int o = (int)(e % Cout);
+    const long tc = e / Cout;
+    const int c = (int)(tc % Cin), t = (int)(tc / Cin);
+    const size_t stride = (size_t)NT * CinP * CoutB;
+    const float* s = slabs + ((size_t)t * CinP + c) * CoutB + o;
+    float acc = 0.f;
+    for (int k = 0; k < nslices; ++k) acc += s[(size_t)k * stride];
+    float* d = dst + o * so + c * sc + tt.off[t];
+    *d = accumulate ? *d + acc : acc;
+}
+
+void geometry(const c2s_wgrad_desc* d, int TP, int* log2pc, int* tiles_x, int* tiles_y) {
+    int l2 = 5;
+    while (l2 > 2 && (1 << l2) > d->Wout) --l2;
+    *log2pc = l2;
+    *tiles_x = cdiv(d->Wout, 1 << l2);
+    *tiles_y = cdiv(d->Hout, TP >> l2);
+}
+
+template <int K, int S>
+int launch_wgrad(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
+    using C = WCfg<K, S>;
+    geometry(d, C::TP, &p.log2pc, &p.tiles_x, &p.tiles_y);
+    p.ntiles = d->N * p.tiles_x * p.tiles_y;
+    const int PC = 1 << p.log2pc, PR = C::TP >> p.log2pc;
+    const int plane = ((PR - 1) * S + K) * ((PC - 1) * S + K);
+    const size_t lds = ((size_t)32 * (plane | 1) + (size_t)64 * (C::TP + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<K, S>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
+    hipLaunchKernelGGL((conv_wgrad_kernel<K, S>), grid, dim3(256), lds, st, p);
+    C2S_CHECK_LAUNCH("conv_wgrad");
+    return C2S_OK;
+}
+
+int check(const c2s_wgrad_desc* d) {
+    C2S_REQUIRE(d && d->N > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "wgrad: bad channels");
+    C2S_REQUIRE(d->KH == d->KW, "wgrad: square kernels only");
+    C2S_REQUIRE(d->nslices > 0, "wgrad: nslices must be positive");
+    C2S_REQUIRE(d->Hin < 1024 && d->Win < 1024, "wgrad: plane too large");
+    return C2S_OK;
+}
+
+}  // namespace
+
+extern "C" size_t c2s_wgrad_workspace_floats(const c2s_wgrad_desc* d) {
+    if (!d) return 0;
+    const size_t CinP = (size_t)cdiv(d->C0 + d->C1, 32) * 32, CoutB = (size_t)cdiv(d->Cout, 64) * 64;
+    return (size_t)d->nslices * d->KH * d->KW * CinP * CoutB;
+}
+
+extern "C" int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const float* src1, const float* gout,
+                              float* slabs, size_t slab_floats, const int* valid, void* stream) {
+    if (int rc = check(d)) return rc;
+    C2S_REQUIRE(src0 && gout && slabs && (d->C1 == 0 || src1), "wgrad: null pointer");
+    C2S_REQUIRE(slab_floats >= c2s_wgrad_workspace_floats(d), "wgrad: slab workspace too small");
+    WgradParams p;
+    p.src0 = src0; p.src1 = src1; p.gout = gout; p.slabs = slabs; p.valid = valid;
+    p.N = d->N; p.C0 = d->C0; p.C1 = d->C1; p.Hin = d->Hin; p.Win = d->Win; p.Cout = d->Cout;
+    p.Hout = d->Hout; p.Wout = d->Wout; p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.pad_mode = d->pad_mode;
+    p.nslices = d->nslices;
+    p.CinP = cdiv(d->C0 + d->C1, 32) * 32;
+    p.CoutB = cdiv(d->Cout, 64) * 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->KH == 3 && d->S == 1) return launch_wgrad<3, 1>(d, p, st);
+    if (d->KH == 1 && d->S == 1) return launch_wgrad<1, 1>(d, p, st);
+    if (d->KH == 4 && d->S == 2) return launch_wgrad<4, 2>(d, p, st);
+    c2s_set_error("wgrad: unsupported (K=%d,S=%d)", d->KH, d->S);
+    return C2S_EINVAL;
+}
+
+extern "C" int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, float* dst, long stride_o, long stride_c,
+                                const int* host_tap_off, int accumulate, void* stream) {
+    if (int rc = check(d)) return rc;
+    C2S_REQUIRE(slabs && dst && host_tap_off, "wgrad_reduce: null pointer");
+    const int NT = d->KH * d->KW;
+    TapTable tt;
+    for (int i = 0; i < 16; ++i) tt.off[i] = i < NT ? host_tap_off[i] : 0;
+    const int Cin = d->C0 + d->C1;
+    const long total = (long)NT * Cin * d->Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, slabs, dst,
+                       d->nslices, NT, Cin, d->Cout, cdiv(Cin, 32) * 32, cdiv(d->Cout, 64) * 64, stride_o, stride_c, tt,
+                       accumulate);
+    C2S_CHECK_LAUNCH("wgrad_reduce");
+    return C2S_OK;
+}

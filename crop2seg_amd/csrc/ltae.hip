@@ -1,0 +1,606 @@
+// L-TAE temporal attention for gfx950, fused and re-associated:
+//
+//   reference (src/backbones/tae.py:451-481, 738-847) per pixel sequence x[T,C]:
+//     xhat = GroupNorm_16(x over (C/16 x T))            e_t = Wc xhat_t + bc + pe_t        (C -> 256)
+//     k_t  = Wk e_t + bk ; score[h,t] = q_h . k_t[4h:4h+4] / 2 ; attn = dropout(softmax_T(mask(score)))
+//     emb[16h+j] = sum_t attn[h,t] e_t[16h+j]
+//   here:
+//     score[h,t] = U[h,:] . xhat_t + s0[b,t,h]          U = q_h^T Wk_h Wc / 2   (16 x C, folded on the host)
+//     z[h,:]     = sum_t attn[h,t] xhat_t               (per head, C-vector)
+//     emb[16h+j] = Wc[16h+j,:] . z[h,:] + (sum_t attn[h,t]) bc[16h+j] + sum_t attn[h,t] pe[b,t,j]
+//   i.e. the C->256 projection runs once per pixel instead of once per (pixel, t): 1/T of the FLOPs and
+//   the [P,T,256] tensors of the reference are never materialised.
+//
+// Layout: everything stays NCHW.  x [B,T,C,hw], attn [16,B,T,hw], emb [B,256,hw]: the pixel index is the
+// fastest axis, so a workgroup owns 16 adjacent pixels and its 256 threads are (pixel, head|group)
+// pairs: lanes 0..15 of every 16-lane group read/write 64 contiguous bytes.
+#include "common.h"
+
+namespace {
+
+constexpr int NH = 16;   // heads == GroupNorm groups (tae.py:428-435)
+constexpr int DV = 16;   // d_model / n_head
+
+struct LtaeParams {
+    const float* x; const float* gamma; const float* beta; const float* U; const float* s0;
+    const float* Wc; const float* bc; const float* pe; const int* valid;
+    float* attn; float* attn_pre; float* emb; float* stats;
+    // backward
+    const float* g_emb; const float* g_attn; const float* attn_in; const float* attn_pre_in; const float* stats_in;
+    float* gx; float* GS; float* V; float* Z; float* part_s0; float* part_bc; float* part_gb;
+    const float* keep;
+    int B, T, C, HW;
+    float eps, drop_p;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_total, long pidx, int t) {
+    if (p.drop_p <= 0.f) return 1.f;
+    const long idx = ((long)h * P_total + pidx) * p.T + t;
+    const float inv = 1.f / (1.f - p.drop_p);
+    if (p.keep != nullptr) return p.keep[idx] != 0.f ? inv : 0.f;
+    return c2s_uniform(p.seed, (uint64_t)idx) >= p.drop_p ? inv : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
+    extern __shared__ float lds[];
+    const int C = p.C, T = p.T, HW = p.HW;
+    float* Ul = lds;              // [16][C]
+    float* ABl = Ul + NH * C;     // [C][16][2]
+    float* Sl = ABl + C * 32;     // [T][16][16]
+    const int tid = threadIdx.x, px = tid & 15, hh = tid >> 4;
+    const int tiles_per_b = HW / 16;
+    const int b = blockIdx.x / tiles_per_b, pix = (blockIdx.x % tiles_per_b) * 16 + px;
+    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
+    const int cpg = C / NH;
+    for (int i = tid; i < NH * C; i += 256) Ul[i] = p.U[i];
+    const float* xb = p.x + (size_t)b * T * C * HW + pix;
+
+    // ---- phase 1: GroupNorm statistics of group hh (padded frames included, tae.py:461)
+    {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t)
+            for (int cc = 0; cc < cpg; ++cc) s += xb[(size_t)(t * C + hh * cpg + cc) * HW];
+        const float inv_n = 1.f / (float)(cpg * T);
+        const float mean = s * inv_n;
+        float m2 = 0.f;
+        for (int t = 0; t < T; ++t)
+            for (int cc = 0; cc < cpg; ++cc) {
+                const float d = xb[(size_t)(t * C + hh * cpg + cc) * HW] - mean;
+                m2 += d * d;
+            }
+        const float rstd = rsqrtf(m2 * inv_n + p.eps);
+        p.stats[(pidx * NH + hh) * 2] = mean;
+        p.stats[(pidx * NH + hh) * 2 + 1] = rstd;
+        for (int cc = 0; cc < cpg; ++cc) {
+            const int c = hh * cpg + cc;
+            const float a = p.gamma[c] * rstd;
+            ABl[(c * 16 + px) * 2] = a;
+            ABl[(c * 16 + px) * 2 + 1] = p.beta[c] - mean * a;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: scores of head hh, masking, softmax over T, dropout
+    float mx = -3.0e38f;
+    for (int t = 0; t < T; ++t) {
+        float s = p.s0[(b * T + t) * NH + hh];
+        const float* xt = xb + (size_t)t * C * HW;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float xv = xt[(size_t)c * HW];
+            s += Ul[hh * C + c] * (ABl[(c * 16 + px) * 2] * xv + ABl[(c * 16 + px) * 2 + 1]);
+        }
+        if (p.valid != nullptr && p.valid[b * T + t] == 0) s = -1e6f;   // tae.py:831
+        Sl[(t * 16 + hh) * 16 + px] = s;
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float e = __expf(Sl[(t * 16 + hh) * 16 + px] - mx);
+        Sl[(t * 16 + hh) * 16 + px] = e;
+        den += e;
+    }
+    const float inv_den = 1.f / den;
+    float asum = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float a = Sl[(t * 16 + hh) * 16 + px] * inv_den;
+        const float ad = a * keep_scale(p, hh, Ptot, pidx, t);
+        const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
+        if (p.attn_pre != nullptr) p.attn_pre[o] = a;
+        p.attn[o] = ad;
+        Sl[(t * 16 + hh) * 16 + px] = ad;
+        asum += ad;
+    }
+    if (p.emb == nullptr) return;   // W-TAE: attention masks only (tae.py:619)
+
+    // ---- phase 3: z = sum_t attn * xhat ; emb slice of head hh
+    float o[DV];
+#pragma unroll
+    for (int j = 0; j < DV; ++j) o[j] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float z = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) z += Sl[(t * 16 + hh) * 16 + px] * xb[(size_t)(t * C + c) * HW];
+        const float zz = ABl[(c * 16 + px) * 2] * z + ABl[(c * 16 + px) * 2 + 1] * asum;
+#pragma unroll
+        for (int j = 0; j < DV; ++j) o[j] += p.Wc[(size_t)(hh * DV + j) * C + c] * zz;
+    }
+#pragma unroll
+    for (int j = 0; j < DV; ++j) o[j] += asum * p.bc[hh * DV + j];
+    for (int t = 0; t < T; ++t) {
+        const float ad = Sl[(t * 16 + hh) * 16 + px];
+#pragma unroll
+        for (int j = 0; j < DV; ++j) o[j] += ad * p.pe[(b * T + t) * DV + j];
+    }
+#pragma unroll
+    for (int j = 0; j < DV; ++j) p.emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] = o[j];
+}
+
+// ------------------------------------------------------------------------------------------ backward, part 1
+// thread = (pixel, head): softmax/dropout backward -> GS (d score), V = sum_t gs xhat, Z = sum_t attn xhat,
+// per-tile partials of d s0 and d bc.
+__global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
+    extern __shared__ float lds[];
+    const int C = p.C, T = p.T, HW = p.HW;
+    float* ABl = lds;             // [C][16][2]
+    float* Dl = ABl + C * 32;     // [T][16][16]  dot -> ga -> gs
+    float* Al = Dl + T * 256;     // [T][16][16]  attn (post-dropout)
+    const int tid = threadIdx.x, px = tid & 15, hh = tid >> 4;
+    const int tiles_per_b = HW / 16;
+    const int b = blockIdx.x / tiles_per_b, pix = (blockIdx.x % tiles_per_b) * 16 + px;
+    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
+    const int cpg = C / NH;
+    const float* xb = p.x + (size_t)b * T * C * HW + pix;
+    {
+        const float mean = p.stats_in[(pidx * NH + hh) * 2], rstd = p.stats_in[(pidx * NH + hh) * 2 + 1];
+        for (int cc = 0; cc < cpg; ++cc) {
+            const int c = hh * cpg + cc;
+            const float a = p.gamma[c] * rstd;
+            ABl[(c * 16 + px) * 2] = a;
+            ABl[(c * 16 + px) * 2 + 1] = p.beta[c] - mean * a;
+        }
+    }
+    float ge[DV];
+    float gebc = 0.f;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+        ge[j] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] : 0.f;
+        gebc += ge[j] * p.bc[hh * DV + j];
+    }
+    for (int t = 0; t < T; ++t) {
+        Dl[(t * 16 + hh) * 16 + px] = 0.f;
+        Al[(t * 16 + hh) * 16 + px] = p.attn_in[((size_t)(hh * p.B + b) * T + t) * HW + pix];
+    }
+    __syncthreads();
+    // dot[t] = sum_c r_c * xhat[t,c],  r_c = sum_j ge[j] Wc[16h+j][c]
+    if (p.g_emb != nullptr) {
+        for (int c = 0; c < C; ++c) {
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < DV; ++j) r += ge[j] * p.Wc[(size_t)(hh * DV + j) * C + c];
+            const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
+#pragma unroll 4
+            for (int t = 0; t < T; ++t) Dl[(t * 16 + hh) * 16 + px] += r * (a * xb[(size_t)(t * C + c) * HW] + bb);
+        }
+    }
+    // softmax / dropout backward
+    float dsum = 0.f, asum = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
+        float gap = Dl[(t * 16 + hh) * 16 + px] + gebc;
+        if (p.g_attn != nullptr) gap += p.g_attn[o];
+#pragma unroll
+        for (int j = 0; j < DV; ++j) gap += ge[j] * p.pe[(b * T + t) * DV + j];
+        const float ga = gap * keep_scale(p, hh, Ptot, pidx, t);
+        dsum += p.attn_pre_in[o] * ga;
+        Dl[(t * 16 + hh) * 16 + px] = ga;
+        asum += Al[(t * 16 + hh) * 16 + px];
+    }
+    for (int t = 0; t < T; ++t) {
+        const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
+        const float gs = p.attn_pre_in[o] * (Dl[(t * 16 + hh) * 16 + px] - dsum);
+        Dl[(t * 16 + hh) * 16 + px] = gs;
+        p.GS[o] = gs;
+        // d s0[b,t,h]: sum over the 16 pixels of the tile
+        float r = gs;
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
+        if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + hh] = r;
+    }
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+        float r = ge[j] * asum;
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
+        if (px == 0) p.part_bc[(size_t)blockIdx.x * NH * DV + hh * DV + j] = r;
+    }
+    // V[b,h,c,pix] = sum_t gs xhat ; Z[b,h,c,pix] = sum_t attn xhat
+    float gssum = 0.f;
+    for (int t = 0; t < T; ++t) gssum += Dl[(t * 16 + hh) * 16 + px];
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f, z = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) {
+            const float xv = xb[(size_t)(t * C + c) * HW];
+            v += Dl[(t * 16 + hh) * 16 + px] * xv;
+            z += Al[(t * 16 + hh) * 16 + px] * xv;
+        }
+        const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
+        const size_t o = (((size_t)b * NH + hh) * C + c) * HW + pix;
+        p.V[o] = a * v + bb * gssum;
+        p.Z[o] = a * z + bb * asum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward, part 2
+// thread = (pixel, group): d xhat = sum_h (attn r_h + gs U_h), then per-pixel GroupNorm backward.
+__global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
+    extern __shared__ float lds[];
+    const int C = p.C, T = p.T, HW = p.HW;
+    float* Ul = lds;                // [16][C]
+    float* GEl = Ul + NH * C;       // [256][16]
+    float* Gl = GEl + 256 * 16;     // [T][16][16] gs
+    float* Al = Gl + T * 256;       // [T][16][16] attn
+    const int tid = threadIdx.x, px = tid & 15, g = tid >> 4;
+    const int tiles_per_b = HW / 16;
+    const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * 16, pix = pix0 + px;
+    const long pidx = (long)b * HW + pix;
+    const int cpg = C / NH;
+    for (int i = tid; i < NH * C; i += 256) Ul[i] = p.U[i];
+    for (int i = tid; i < 256 * 16; i += 256) {
+        const int ch = i >> 4, q = i & 15;
+        GEl[i] = p.g_emb != nullptr ? p.g_emb[((size_t)b * 256 + ch) * HW + pix0 + q] : 0.f;
+    }
+    for (int i = tid; i < T * 256; i += 256) {
+        const int q = i & 15, h = (i >> 4) & 15, t = i >> 8;
+        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix0 + q;
+        Gl[i] = p.GS[o];
+        Al[i] = p.attn_in[o];
+    }
+    __syncthreads();
+    const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
+    const float* xb = p.x + (size_t)b * T * C * HW + pix;
+    float* gxb = p.gx + (size_t)b * T * C * HW + pix;
+    float m1 = 0.f, m2 = 0.f;
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = g * cpg + cc;
+        float r[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < DV; ++j) s += GEl[(h * DV + j) * 16 + px] * p.Wc[(size_t)(h * DV + j) * C + c];
+            r[h] = s;
+        }
+        float u[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) u[h] = Ul[h * C + c];
+        const float gm = p.gamma[c];
+        float dg = 0.f, db = 0.f;
+        for (int t = 0; t < T; ++t) {
+            float gxh = 0.f;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) gxh += Al[(t * 16 + h) * 16 + px] * r[h] + Gl[(t * 16 + h) * 16 + px] * u[h];
+            const float xn = (xb[(size_t)(t * C + c) * HW] - mean) * rstd;
+            dg += gxh * xn;
+            db += gxh;
+            const float dxn = gxh * gm;
+            m1 += dxn;
+            m2 += dxn * xn;
+            gxb[(size_t)(t * C + c) * HW] = dxn;
+        }
+        dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
+        db += __shfl_xor(db, 1, 64); db += __shfl_xor(db, 2, 64); db += __shfl_xor(db, 4, 64); db += __shfl_xor(db, 8, 64);
+        if (px == 0) {
+            p.part_gb[((size_t)blockIdx.x * C + c) * 2] = dg;
+            p.part_gb[((size_t)blockIdx.x * C + c) * 2 + 1] = db;
+        }
+    }
+    const float inv_n = 1.f / (float)(cpg * T);
+    m1 *= inv_n;
+    m2 *= inv_n;
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = g * cpg + cc;
+        for (int t = 0; t < T; ++t) {
+            const size_t o = (size_t)(t * C + c) * HW;
+            const float xn = (xb[o] - mean) * rstd;
+            gxb[o] = rstd * (gxb[o] - m1 - xn * m2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ reductions
+// out[grp][k] = sum_{i<count} part[(grp*count + i)*K + k]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int count, int K,
+                                       long total) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long grp = e / K;
+    const int k = (int)(e % K);
+    double s = 0.0;
+    for (int i = 0; i < count; ++i) s += part[((size_t)grp * count + i) * K + k];
+    out[e] = (float)s;
+}
+
+// gU[h,c] = sum_{b,pix} V[b,h,c,pix]     one wave per (h,c)
+__global__ __launch_bounds__(64) void sum_over_pixels_kernel(const float* __restrict__ V, float* __restrict__ out, int B,
+                                                             int rows, int HW) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* v = V + ((size_t)b * rows + row) * HW;
+        for (int i = lane; i < HW; i += 64) s += v[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// gWc[16h+j][c] = sum_{b,pix} ge[b,16h+j,pix] * Z[b,h,c,pix]    workgroup per (h,c): 16 j x 16 pixel lanes
+__global__ __launch_bounds__(256) void gwc_kernel(const float* __restrict__ ge, const float* __restrict__ Z,
+                                                  float* __restrict__ gWc, int B, int C, int HW) {
+    const int h = blockIdx.x / C, c = blockIdx.x % C;
+    const int j = threadIdx.x >> 4, q = threadIdx.x & 15;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* z = Z + (((size_t)b * NH + h) * C + c) * HW;
+        const float* g = ge + ((size_t)b * NH * DV + h * DV + j) * HW;
+        for (int i = q; i < HW; i += 16) s += g[i] * z[i];
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+    if (q == 0) gWc[(size_t)(h * DV + j) * C + c] = s;
+}
+
+// per-pixel GroupNorm over channel groups of a [B,C,HW] tensor (tae.py:437-440,488)
+__global__ void pixel_gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats,
+                                    int B, int C, int HW, int groups, float eps) {
+    const long total = (long)B * groups * HW;
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int pix = (int)(e % HW);
+    const long bg = e / HW;
+    const int g = (int)(bg % groups), b = (int)(bg / groups);
+    const int cpg = C / groups;
+    const float* xp = x + ((size_t)b * C + g * cpg) * HW + pix;
+    float s = 0.f;
+    for (int c = 0; c < cpg; ++c) s += xp[(size_t)c * HW];
+    const float mean = s / cpg;
+    float m2 = 0.f;
+    for (int c = 0; c < cpg; ++c) { const float d = xp[(size_t)c * HW] - mean; m2 += d * d; }
+    const float rstd = rsqrtf(m2 / cpg + eps);
+    stats[e * 2] = mean; stats[e * 2 + 1] = rstd;
+    float* yp = y + ((size_t)b * C + g * cpg) * HW + pix;
+    for (int c = 0; c < cpg; ++c)
+        yp[(size_t)c * HW] = (xp[(size_t)c * HW] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c];
+}
+
+// gx, and per-thread-block partials of dgamma/dbeta: part[block][C][2] via atomics-free two-level scheme:
+// each thread handles one (b,g,pix); dgamma/dbeta partials are accumulated with a wave reduction when the
+// 64 lanes share (b,g) (HW % 64 == 0) and written per wave.
+__global__ __launch_bounds__(64) void pixel_gn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                          float* __restrict__ gx, float* __restrict__ part, int B, int C,
+                                                          int HW, int groups, int chunks) {
+    // grid = B*groups*chunks waves; wave handles pixels [chunk*len, ...) of one (b,g)
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x % chunks;
+    const int bg = blockIdx.x / chunks;
+    const int g = bg % groups, b = bg / groups;
+    const int cpg = C / groups;
+    const int len = (HW + chunks - 1) / chunks;
+    const int beg = chunk * len, end = (beg + len) < HW ? (beg + len) : HW;
+    float dg[16], db[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { dg[c] = 0.f; db[c] = 0.f; }
+    for (int pix = beg + lane; pix < end; pix += 64) {
+        const long e = ((long)b * groups + g) * HW + pix;
+        const float mean = stats[e * 2], rstd = stats[e * 2 + 1];
+        const float* xp = x + ((size_t)b * C + g * cpg) * HW + pix;
+        const float* gp = gy + ((size_t)b * C + g * cpg) * HW + pix;
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < cpg) {
+                const float xn = (xp[(size_t)c * HW] - mean) * rstd;
+                const float gg = gp[(size_t)c * HW];
+                dg[c] += gg * xn; db[c] += gg;
+                const float dxn = gg * gamma[g * cpg + c];
+                m1 += dxn; m2 += dxn * xn;
+            }
+        m1 /= cpg; m2 /= cpg;
+        float* gxp = gx + ((size_t)b * C + g * cpg) * HW + pix;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < cpg) {
+                const float xn = (xp[(size_t)c * HW] - mean) * rstd;
+                gxp[(size_t)c * HW] = rstd * (gp[(size_t)c * HW] * gamma[g * cpg + c] - m1 - xn * m2);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (c < cpg) {
+            const float a = wave_sum(dg[c]), bb = wave_sum(db[c]);
+            if (lane == 0) {
+                // part[(b*chunks+chunk)][C][2]
+                const size_t o = (((size_t)b * chunks + chunk) * C + g * cpg + c) * 2;
+                part[o] = a; part[o + 1] = bb;
+            }
+        }
+}
+
+// y[b,c,pix] = x * keep / (1-p), keep indexed pixel-major like the reference's [P, C] activations (tae.py:448)
+__global__ void dropout_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW, float p,
+                                    uint64_t seed, const float* __restrict__ keep) {
+    const long total = (long)B * C * HW;
+    const float inv = 1.f / (1.f - p);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % HW);
+        const long bc = e / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        const long idx = ((long)b * HW + pix) * C + c;
+        const bool k = keep != nullptr ? keep[idx] != 0.f : c2s_uniform(seed, (uint64_t)idx) >= p;
+        y[e] = k ? x[e] * inv : 0.f;
+    }
+}
+
+size_t fwd_lds(const c2s_ltae_desc* d) { return ((size_t)NH * d->C + (size_t)d->C * 32 + (size_t)d->T * 256) * 4; }
+size_t bwd1_lds(const c2s_ltae_desc* d) { return ((size_t)d->C * 32 + (size_t)d->T * 512) * 4; }
+size_t bwd2_lds(const c2s_ltae_desc* d) { return ((size_t)NH * d->C + 256 * 16 + (size_t)d->T * 512) * 4; }
+
+int check(const c2s_ltae_desc* d) {
+    C2S_REQUIRE(d && d->B > 0 && d->T > 0 && d->C > 0 && d->HW > 0, "ltae: bad shape");
+    C2S_REQUIRE(d->n_head == NH && d->d_model == NH * DV, "ltae: only n_head=16, d_model=256 are built");
+    C2S_REQUIRE(d->C % NH == 0 && d->C / NH <= 16, "ltae: C must be a multiple of 16 and <= 256");
+    C2S_REQUIRE(d->HW % 16 == 0, "ltae: h*w must be a multiple of 16");
+    C2S_REQUIRE(bwd2_lds(d) <= 160 * 1024 && fwd_lds(d) <= 160 * 1024, "ltae: T*C too large for the LDS tile");
+    C2S_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "ltae: bad dropout p");
+    return C2S_OK;
+}
+
+void fill(LtaeParams& p, const c2s_ltae_desc* d) {
+    p.B = d->B; p.T = d->T; p.C = d->C; p.HW = d->HW; p.eps = d->eps; p.drop_p = d->dropout_p; p.seed = d->seed;
+    p.keep = d->keep;
+}
+
+}  // namespace
+
+extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                                 const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                                 const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
+                                 void* stream) {
+    if (int rc = check(d)) return rc;
+    C2S_REQUIRE(x && gamma && beta && U && s0 && attn && stats, "ltae_fwd: null pointer");
+    C2S_REQUIRE(emb == nullptr || (Wc && bc && pe), "ltae_fwd: embedding output needs Wc, bc, pe");
+    LtaeParams p = {};
+    fill(p, d);
+    p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.s0 = s0; p.Wc = Wc; p.bc = bc; p.pe = pe; p.valid = valid;
+    p.attn = attn; p.attn_pre = attn_pre; p.emb = emb; p.stats = stats;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * (d->HW / 16)), dim3(256), fwd_lds(d), (hipStream_t)stream, p);
+    C2S_CHECK_LAUNCH("ltae_fwd");
+    return C2S_OK;
+}
+
+// workspace: GS [16,B,T,HW] | V [B,16,C,HW] | Z [B,16,C,HW] | part_s0 [tiles][T][16] | part_bc [tiles][256]
+//            | part_gb [tiles][C][2]
+extern "C" size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d) {
+    if (!d) return 0;
+    const size_t tiles = (size_t)d->B * (d->HW / 16);
+    return (size_t)NH * d->B * d->T * d->HW + 2 * (size_t)d->B * NH * d->C * d->HW + tiles * d->T * NH + tiles * 256 +
+           tiles * d->C * 2;
+}
+
+extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                                 const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                                 const int* valid, const float* attn, const float* attn_pre, const float* stats,
+                                 const float* g_emb, const float* g_attn, float* gx, float* gU, float* gs0, float* gWc,
+                                 float* gbc, float* ggamma, float* gbeta, float* workspace, size_t ws_floats,
+                                 void* stream) {
+    if (int rc = check(d)) return rc;
+    C2S_REQUIRE(x && gamma && beta && U && Wc && bc && pe && attn && attn_pre && stats && gx && gU && gs0 && gWc && gbc &&
+                    ggamma && gbeta && workspace,
+                "ltae_bwd: null pointer");
+    C2S_REQUIRE(ws_floats >= c2s_ltae_bwd_workspace_floats(d), "ltae_bwd: workspace too small");
+    (void)s0; (void)valid;
+    const size_t tiles = (size_t)d->B * (d->HW / 16);
+    LtaeParams p = {};
+    fill(p, d);
+    p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.Wc = Wc; p.bc = bc; p.pe = pe;
+    p.attn_in = attn; p.attn_pre_in = attn_pre; p.stats_in = stats; p.g_emb = g_emb; p.g_attn = g_attn; p.gx = gx;
+    p.GS = workspace;
+    p.V = p.GS + (size_t)NH * d->B * d->T * d->HW;
+    p.Z = p.V + (size_t)d->B * NH * d->C * d->HW;
+    p.part_s0 = p.Z + (size_t)d->B * NH * d->C * d->HW;
+    p.part_bc = p.part_s0 + tiles * d->T * NH;
+    p.part_gb = p.part_bc + tiles * 256;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
+    C2S_CHECK_LAUNCH("ltae_bwd_heads");
+    hipLaunchKernelGGL(ltae_bwd_gx_kernel, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
+    C2S_CHECK_LAUNCH("ltae_bwd_gx");
+    // reductions
+    const int tpb = d->HW / 16;
+    {   // gs0[b][t][h] = sum over the tiles of b
+        const long total = (long)d->B * d->T * NH;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.part_s0, gs0, tpb,
+                           d->T * NH, total);
+        C2S_CHECK_LAUNCH("ltae_reduce_s0");
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.part_bc, gbc, (int)tiles, 256, (long)256);
+    C2S_CHECK_LAUNCH("ltae_reduce_bc");
+    {   // interleaved (dgamma, dbeta) -> two outputs: reduce into a [C][2] scratch then split (reuse part_bc tail)
+        float* gb = p.part_bc;   // part_bc is consumed above; 2*C <= 256 floats fit in its first entries
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * d->C, 256)), dim3(256), 0, st, p.part_gb, gb, (int)tiles,
+                           2 * d->C, (long)2 * d->C);
+        C2S_CHECK_LAUNCH("ltae_reduce_gb");
+        hipMemcpy2DAsync(ggamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
+        hipMemcpy2DAsync(gbeta, sizeof(float), gb + 1, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
+    }
+    hipLaunchKernelGGL(sum_over_pixels_kernel, dim3(NH * d->C), dim3(64), 0, st, p.V, gU, d->B, NH * d->C, d->HW);
+    C2S_CHECK_LAUNCH("ltae_gU");
+    if (g_emb != nullptr) {
+        hipLaunchKernelGGL(gwc_kernel, dim3(NH * d->C), dim3(256), 0, st, g_emb, p.Z, gWc, d->B, d->C, d->HW);
+        C2S_CHECK_LAUNCH("ltae_gWc");
+    } else {
+        hipMemsetAsync(gWc, 0, (size_t)256 * d->C * sizeof(float), st);
+    }
+    return C2S_OK;
+}
+
+extern "C" int c2s_pixel_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B,
+                                int C, int HW, int groups, float eps, void* stream) {
+    C2S_REQUIRE(x && gamma && beta && y && stats && groups > 0 && C % groups == 0 && C / groups <= 16, "pixel_gn_fwd: bad args");
+    const long total = (long)B * groups * HW;
+    hipLaunchKernelGGL(pixel_gn_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       stats, B, C, HW, groups, eps);
+    C2S_CHECK_LAUNCH("pixel_gn_fwd");
+    return C2S_OK;
+}
+
+extern "C" size_t c2s_pixel_gn_bwd_workspace_floats(int B, int C, int HW) {
+    const int chunks = cdiv(HW, 256);
+    return (size_t)B * chunks * C * 2 + 2 * (size_t)C;
+}
+
+extern "C" int c2s_pixel_gn_bwd(const float* x, const float* gy, const float* gamma, const float* stats, float* gx,
+                                float* dgamma, float* dbeta, int B, int C, int HW, int groups, float* workspace,
+                                size_t ws_floats, void* stream) {
+    C2S_REQUIRE(x && gy && gamma && stats && gx && dgamma && dbeta && workspace, "pixel_gn_bwd: null pointer");
+    C2S_REQUIRE(groups > 0 && C % groups == 0 && C / groups <= 16, "pixel_gn_bwd: bad groups");
+    C2S_REQUIRE(ws_floats >= c2s_pixel_gn_bwd_workspace_floats(B, C, HW), "pixel_gn_bwd: workspace too small");
+    const int chunks = cdiv(HW, 256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pixel_gn_bwd_kernel, dim3(B * groups * chunks), dim3(64), 0, st, x, gy, gamma, stats, gx, workspace,
+                       B, C, HW, groups, chunks);
+    C2S_CHECK_LAUNCH("pixel_gn_bwd");
+    float* gb = workspace + (size_t)B * chunks * C * 2;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, workspace, gb, B * chunks, 2 * C,
+                       (long)2 * C);
+    C2S_CHECK_LAUNCH("pixel_gn_reduce");
+    hipMemcpy2DAsync(dgamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), C, hipMemcpyDeviceToDevice, st);
+    hipMemcpy2DAsync(dbeta, sizeof(float), gb + 1, 2 * sizeof(float), sizeof(float), C, hipMemcpyDeviceToDevice, st);
+    return C2S_OK;
+}
+
+extern "C" int c2s_dropout_nchw(const float* x, float* y, int B, int C, int HW, float p, uint64_t seed, const float* keep,
+                                void* stream) {
+    C2S_REQUIRE(x && y && p >= 0.f && p < 1.f, "dropout: bad args");
+    const long total = (long)B * C * HW;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(dropout_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, C, HW, p, seed, keep);
+    C2S_CHECK_LAUNCH("dropout");
+    return C2S_OK;
+}

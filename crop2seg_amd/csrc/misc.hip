@@ -1,0 +1,343 @@
+// Small kernels of the hot path: frame flags, depthwise convolution (W-TAE), cross-entropy, flat Adam,
+// fill / add.  All HBM- or latency-bound; see DESIGN.md for the per-kernel roofline notes.
+#include <stdarg.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void c2s_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int c2s_abi_version(void) { return 1; }
+extern "C" const char* c2s_last_error(void) { return g_err; }
+extern "C" int c2s_device_cus(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    return prop.multiProcessorCount;
+}
+
+namespace {
+
+// ---------------------------------------------------------------- frame flags (utae.py:201-203)
+__global__ __launch_bounds__(256) void frame_flags_kernel(const float* __restrict__ x, int* __restrict__ valid,
+                                                          long frame_elems, float pad_value, int chunks) {
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const long len = (frame_elems + chunks - 1) / chunks;
+    const long beg = chunk * len, end = (beg + len) < frame_elems ? (beg + len) : frame_elems;
+    const float* xf = x + (size_t)n * frame_elems;
+    int any = 0;
+    for (long i = beg + threadIdx.x; i < end; i += 256) any |= (xf[i] != pad_value);
+    any = __any(any);
+    if ((threadIdx.x & 63) == 0 && any) atomicOr(valid + n, 1);
+}
+
+// ---------------------------------------------------------------- depthwise conv (conv.py:18-24)
+__global__ void dw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                              const int* __restrict__ valid, int N, int C, int Hin, int Win, int K, int S, int pad,
+                              int reflect) {
+    const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    const long total = (long)N * C * Ho * Wo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(e % Wo);
+        long r = e / Wo;
+        const int oy = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C), n = (int)(r / C);
+        if (valid != nullptr && valid[n] == 0) continue;
+        const float* ip = in + ((size_t)n * C + c) * Hin * Win;
+        const float* wp = w + (size_t)c * K * K;
+        float acc = 0.f;
+        for (int ky = 0; ky < K; ++ky) {
+            int gy = oy * S - pad + ky;
+            if (reflect) gy = reflect_idx(gy, Hin); else if (gy < 0 || gy >= Hin) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                int gx = ox * S - pad + kx;
+                if (reflect) gx = reflect_idx(gx, Win); else if (gx < 0 || gx >= Win) continue;
+                acc += wp[ky * K + kx] * ip[gy * Win + gx];
+            }
+        }
+        out[e] = acc;
+    }
+}
+
+__device__ __forceinline__ int preimages(int j, int n, int pad, int reflect, int* q) {
+    int k = 0;
+    q[k++] = j;
+    if (reflect && pad >= 1) {
+        if (j == 1) q[k++] = -1;
+        if (j == n - 2) q[k++] = n;
+    }
+    return k;
+}
+
+__global__ void dw_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w, float* __restrict__ gin,
+                                const int* __restrict__ valid, int N, int C, int Hin, int Win, int K, int S, int pad,
+                                int reflect) {
+    const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    const long total = (long)N * C * Hin * Win;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int jx = (int)(e % Win);
+        long r = e / Win;
+        const int jy = (int)(r % Hin); r /= Hin;
+        const int c = (int)(r % C), n = (int)(r / C);
+        if (valid != nullptr && valid[n] == 0) { gin[e] = 0.f; continue; }
+        const float* gp = gout + ((size_t)n * C + c) * Ho * Wo;
+        const float* wp = w + (size_t)c * K * K;
+        int qy[3], qx[3];
+        const int ny = preimages(jy, Hin, pad, reflect, qy), nx = preimages(jx, Win, pad, reflect, qx);
+        float acc = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int ky = 0; ky < K; ++ky) {
+                const int ty = qy[a] + pad - ky;
+                if (ty < 0 || ty % S != 0 || ty / S >= Ho) continue;
+                for (int b = 0; b < nx; ++b)
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int tx = qx[b] + pad - kx;
+                        if (tx < 0 || tx % S != 0 || tx / S >= Wo) continue;
+                        acc += wp[ky * K + kx] * gp[(ty / S) * Wo + tx / S];
+                    }
+            }
+        gin[e] = acc;
+    }
+}
+
+// partial[n][c][k] : one workgroup per (n, c)
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                       float* __restrict__ partial, const int* __restrict__ valid, int C,
+                                                       int Hin, int Win, int K, int S, int pad, int reflect) {
+    __shared__ float red[4][16];
+    const int n = blockIdx.x / C, c = blockIdx.x % C;
+    const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    if (valid == nullptr || valid[n] != 0) {
+        const float* ip = in + ((size_t)n * C + c) * Hin * Win;
+        const float* gp = gout + ((size_t)n * C + c) * Ho * Wo;
+        for (int e = threadIdx.x; e < Ho * Wo; e += 256) {
+            const int oy = e / Wo, ox = e % Wo;
+            const float g = gp[e];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < K * K) {
+                    int gy = oy * S - pad + k / K, gx = ox * S - pad + k % K;
+                    bool ok = true;
+                    if (reflect) { gy = reflect_idx(gy, Hin); gx = reflect_idx(gx, Win); }
+                    else ok = gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+                    if (ok) acc[k] += g * ip[gy * Win + gx];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float s = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K)
+        partial[(size_t)blockIdx.x * K * K + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int N, int CKK) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CKK) return;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += partial[(size_t)n * CKK + i];
+    gw[i] = (float)s;
+}
+
+// ---------------------------------------------------------------- cross entropy (train.py:463-468)
+// per block partial (sum w*nll, sum w) -> ws[2*blocks]; finalize -> ws_tot[2]; grad kernel uses ws_tot[1]
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ cw, float* __restrict__ part, int B, int K,
+                                                     int HW) {
+    __shared__ float red[4][2];
+    const long total = (long)B * HW;
+    float num = 0.f, den = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % HW), b = (int)(e / HW);
+        const float* lp = logits + (size_t)b * K * HW + pix;
+        float mx = lp[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[(size_t)k * HW]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += __expf(lp[(size_t)k * HW] - mx);
+        const int y = (int)target[e];
+        const float w = cw[y];
+        num += w * (mx + __logf(s) - lp[(size_t)y * HW]);
+        den += w;
+    }
+    num = wave_sum(num); den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[blockIdx.x * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ part, float* __restrict__ tot, float* __restrict__ loss,
+                                   int blocks) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double num = 0, den = 0;
+    for (int i = 0; i < blocks; ++i) { num += part[i * 2]; den += part[i * 2 + 1]; }
+    tot[0] = (float)num; tot[1] = (float)den;
+    *loss = (float)(num / den);
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ cw, const float* __restrict__ tot,
+                                                     float* __restrict__ glogits, int B, int K, int HW) {
+    const long total = (long)B * HW;
+    const float inv_den = 1.f / tot[1];
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % HW), b = (int)(e / HW);
+        const float* lp = logits + (size_t)b * K * HW + pix;
+        float* gp = glogits + (size_t)b * K * HW + pix;
+        float mx = lp[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[(size_t)k * HW]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += __expf(lp[(size_t)k * HW] - mx);
+        const int y = (int)target[e];
+        const float w = cw[y] * inv_den, inv_s = 1.f / s;
+        for (int k = 0; k < K; ++k)
+            gp[(size_t)k * HW] = w * (__expf(lp[(size_t)k * HW] - mx) * inv_s - (k == y ? 1.f : 0.f));
+    }
+}
+
+// ---------------------------------------------------------------- Adam (train.py:454, torch defaults)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1, float bc2s,
+                            float gscale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * gscale;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm; v[i] = vv;
+        const float denom = sqrtf(vv) / bc2s + eps;
+        p[i] -= (lr / bc1) * (mm / denom);
+    }
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void add_kernel(float* __restrict__ d, const float* __restrict__ s, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] += s[i];
+}
+
+inline int grid_for(long n, int cap = 4096) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+constexpr int CE_BLOCKS = 512;
+
+}  // namespace
+
+extern "C" int c2s_frame_flags(const float* x, int* valid, int N, long frame_elems, float pad_value, void* stream) {
+    C2S_REQUIRE(x && valid && N > 0 && frame_elems > 0, "frame_flags: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(valid, 0, (size_t)N * sizeof(int), st);
+    int chunks = (int)((frame_elems + 16383) / 16384);
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(frame_flags_kernel, dim3(N * chunks), dim3(256), 0, st, x, valid, frame_elems, pad_value, chunks);
+    C2S_CHECK_LAUNCH("frame_flags");
+    return C2S_OK;
+}
+
+static int dw_check(int N, int C, int Hin, int Win, int K, int S, int pad, int pad_mode) {
+    C2S_REQUIRE(N > 0 && C > 0 && Hin > 0 && Win > 0, "dwconv: bad shape");
+    C2S_REQUIRE(K >= 1 && K <= 4 && S >= 1 && pad >= 0 && pad <= 1, "dwconv: unsupported kernel/stride/pad");
+    if (pad_mode == C2S_PAD_REFLECT) C2S_REQUIRE(Hin >= 2 && Win >= 2, "dwconv: reflect needs planes >= 2x2");
+    return C2S_OK;
+}
+
+extern "C" int c2s_dwconv_fwd(const float* in, const float* w, float* out, const int* valid, int N, int C, int Hin,
+                              int Win, int K, int S, int pad, int pad_mode, void* stream) {
+    if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
+    C2S_REQUIRE(in && w && out, "dwconv_fwd: null pointer");
+    const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_for((long)N * C * Ho * Wo, 16384)), dim3(256), 0, (hipStream_t)stream, in, w,
+                       out, valid, N, C, Hin, Win, K, S, pad, pad_mode == C2S_PAD_REFLECT);
+    C2S_CHECK_LAUNCH("dwconv_fwd");
+    return C2S_OK;
+}
+
+extern "C" int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, const int* valid, int N, int C, int Hin,
+                                int Win, int K, int S, int pad, int pad_mode, void* stream) {
+    if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
+    C2S_REQUIRE(gout && w && gin, "dwconv_dgrad: null pointer");
+    hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)N * C * Hin * Win, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       gout, w, gin, valid, N, C, Hin, Win, K, S, pad, pad_mode == C2S_PAD_REFLECT);
+    C2S_CHECK_LAUNCH("dwconv_dgrad");
+    return C2S_OK;
+}
+
+extern "C" int c2s_dwconv_wgrad(const float* in, const float* gout, float* partial, float* gw, const int* valid, int N,
+                                int C, int Hin, int Win, int K, int S, int pad, int pad_mode, void* stream) {
+    if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
+    C2S_REQUIRE(in && gout && partial && gw, "dwconv_wgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(N * C), dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, K, S, pad,
+                       pad_mode == C2S_PAD_REFLECT);
+    C2S_CHECK_LAUNCH("dwconv_wgrad");
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv(C * K * K, 256)), dim3(256), 0, st, partial, gw, N, C * K * K);
+    C2S_CHECK_LAUNCH("dwconv_wgrad_reduce");
+    return C2S_OK;
+}
+
+extern "C" size_t c2s_cross_entropy_workspace_floats(int B, int HW) {
+    (void)B; (void)HW;
+    return 2 * CE_BLOCKS + 2;
+}
+
+extern "C" int c2s_cross_entropy(const float* logits, const int64_t* target, const float* class_w, float* loss,
+                                 float* glogits, int B, int K, int HW, float* workspace, size_t ws_floats, void* stream) {
+    C2S_REQUIRE(logits && target && class_w && loss && workspace, "cross_entropy: null pointer");
+    C2S_REQUIRE(ws_floats >= 2 * CE_BLOCKS + 2 && B > 0 && K > 0 && HW > 0, "cross_entropy: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = grid_for((long)B * HW, CE_BLOCKS);
+    float* tot = workspace + 2 * CE_BLOCKS;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, workspace, B, K, HW);
+    C2S_CHECK_LAUNCH("ce_fwd");
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks);
+    C2S_CHECK_LAUNCH("ce_finalize");
+    if (glogits != nullptr) {
+        hipLaunchKernelGGL(ce_bwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, tot, glogits, B, K, HW);
+        C2S_CHECK_LAUNCH("ce_bwd");
+    }
+    return C2S_OK;
+}
+
+extern "C" int c2s_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                             float eps, int step, float grad_scale, void* stream) {
+    C2S_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad args");
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2,
+                       eps, bc1, bc2s, grad_scale);
+    C2S_CHECK_LAUNCH("adam");
+    return C2S_OK;
+}
+
+extern "C" int c2s_fill(float* p, long n, float v, void* stream) {
+    C2S_REQUIRE(p && n >= 0, "fill: bad args");
+    if (n == 0) return C2S_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    C2S_CHECK_LAUNCH("fill");
+    return C2S_OK;
+}
+
+extern "C" int c2s_add_inplace(float* dst, const float* src, long n, void* stream) {
+    C2S_REQUIRE(dst && src && n >= 0, "add: bad args");
+    if (n == 0) return C2S_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    C2S_CHECK_LAUNCH("add");
+    return C2S_OK;
+}

@@ -1,0 +1,592 @@
+"""Host-side execution engine: thin op wrappers over the C ABI (libc2s_hip.so) and an explicit backward tape.
+
+PyTorch is used for device memory (torch.empty on the current HIP device), the current stream and
+nn.Parameter storage only -- every activation-sized computation below is a hand-written HIP kernel.
+The tape is a plain list of closures recorded during the forward pass and replayed in reverse: no
+tracing, no autograd graph, stream-ordered launches only (hipGraph-capturable).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AggDesc, ConvDesc, LtaeDesc, NormDesc, WgradDesc, check, lib
+
+Tensor = torch.Tensor
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _tap_array(offs: Sequence[int]):
+    return (C.c_int * len(offs))(*offs)
+
+
+class Workspace:
+    """Named scratch buffers, grown on demand and reused across calls (never freed inside a step)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, Tensor] = {}
+
+    def get(self, name: str, nfloats: int) -> Tensor:
+        b = self.bufs.get(name)
+        if b is None or b.numel() < nfloats:
+            b = torch.empty(max(int(nfloats), 1), device=self.device, dtype=torch.float32)
+            self.bufs[name] = b
+        return b
+
+
+class Tape:
+    """Reverse-mode tape.  Gradients are keyed by the data pointer of the forward activation, so a tensor and
+    its reshaped views (4-D frames <-> 5-D [B,T,...]) share one gradient buffer."""
+
+    def __init__(self):
+        self.ops: List[Callable[[], None]] = []
+        self.grads: Dict[int, Tensor] = {}
+        self.keep: List[Tensor] = []      # keeps forward tensors alive (ids stay unique)
+
+    def record(self, fn: Callable[[], None]) -> None:
+        self.ops.append(fn)
+
+    def track(self, t: Tensor) -> Tensor:
+        self.keep.append(t)
+        return t
+
+    def grad_of(self, t: Tensor) -> Optional[Tensor]:
+        return self.grads.get(t.data_ptr())
+
+    def pop_grad(self, t: Tensor) -> Optional[Tensor]:
+        return self.grads.pop(t.data_ptr(), None)
+
+    def add_grad(self, t: Tensor, g: Tensor, own: bool = True) -> None:
+        """Accumulate g into the gradient of t.  If t has no gradient yet, g becomes it (own=True) or is copied."""
+        cur = self.grads.get(t.data_ptr())
+        if cur is None:
+            self.grads[t.data_ptr()] = g if own else g.clone()
+        else:
+            check(lib().c2s_add_inplace(cur.data_ptr(), g.data_ptr(), g.numel(), _stream()), "add_inplace")
+
+    def backward(self) -> None:
+        for fn in reversed(self.ops):
+            fn()
+        self.ops.clear()
+        self.keep.clear()
+
+
+class Ctx:
+    """Per-forward context: parameters by name, parameter-gradient views, scratch, tape, mode flags."""
+
+    def __init__(self, params: Dict[str, Tensor], buffers: Dict[str, Tensor], grads: Optional[Dict[str, Tensor]],
+                 ws: Workspace, training: bool, tape: Optional[Tape], eps: float = 1e-5, momentum: float = 0.1):
+        self.p = params
+        self.b = buffers
+        self.g = grads            # name -> gradient tensor (same shape as the parameter), written by backward
+        self.ws = ws
+        self.training = training
+        self.tape = tape
+        self.eps = eps
+        self.momentum = momentum
+        self.device = ws.device
+        self._packed: Dict[Tuple, Tensor] = {}
+        self._gwritten: set = set()
+        cus = lib().c2s_device_cus()
+        self.cus = cus if cus > 0 else 256
+
+    # -- parameter gradient sinks ---------------------------------------------------------------
+    def grad_sink(self, name: str) -> Tuple[Tensor, int]:
+        """Returns (gradient tensor, accumulate flag) for parameter `name`."""
+        acc = 1 if name in self._gwritten else 0
+        self._gwritten.add(name)
+        return self.g[name], acc
+
+    def add_param_grad(self, name: str, g: Tensor) -> None:
+        dst, acc = self.grad_sink(name)
+        if acc:
+            check(lib().c2s_add_inplace(dst.data_ptr(), g.data_ptr(), g.numel(), _stream()), "add_inplace")
+        else:
+            dst.copy_(g.view_as(dst))
+
+    # -- weight packing --------------------------------------------------------------------------
+    def pack(self, key: Tuple, src: Tensor, src_off: int, cin: int, cout: int, ntaps: int, so: int, sc: int,
+             taps: Sequence[int]) -> Tuple[Tensor, int]:
+        """Pack (cached per forward) weights into [ntaps][cin][coutP]."""
+        hit = self._packed.get(key)
+        coutP = (cout + 31) // 32 * 32
+        if hit is not None:
+            return hit, coutP
+        wpk = torch.empty(ntaps * cin * coutP, device=self.device, dtype=torch.float32)
+        check(lib().c2s_pack_weights(src.data_ptr() + 4 * src_off, wpk.data_ptr(), cin, cout, coutP, ntaps, so, sc,
+                                     _tap_array(taps), _stream()), "pack_weights")
+        self._packed[key] = wpk
+        return wpk, coutP
+
+
+# =================================================================================================
+# frame flags
+# =================================================================================================
+def frame_flags(x5: Tensor, pad_value: float) -> Tensor:
+    """valid[n] = any(x[n] != pad_value) (reference: utae.py:201-203, temp_shared_block.py:31)."""
+    B, T = x5.shape[:2]
+    valid = torch.empty(B * T, device=x5.device, dtype=torch.int32)
+    check(lib().c2s_frame_flags(x5.data_ptr(), valid.data_ptr(), B * T, x5[0, 0].numel(), float(pad_value), _stream()),
+          "frame_flags")
+    return valid
+
+
+# =================================================================================================
+# convolutions
+# =================================================================================================
+def _igemm(desc: ConvDesc, src0: Tensor, src1: Optional[Tensor], wpk: Tensor, bias: Optional[Tensor], out: Tensor,
+           valid: Optional[Tensor]) -> None:
+    check(lib().c2s_conv_igemm(C.byref(desc), src0.data_ptr(), _ptr(src1), wpk.data_ptr(), _ptr(bias), out.data_ptr(),
+                               _ptr(valid), _stream()), "conv_igemm")
+
+
+def _wgrad_slices(ctx: Ctx, N: int, Hout: int, Wout: int, S: int, cin: int, cout: int) -> int:
+    TP = 64 if S == 2 else 128
+    l2 = 5
+    while l2 > 2 and (1 << l2) > Wout:
+        l2 -= 1
+    PC = 1 << l2
+    ntiles = N * ((Wout + PC - 1) // PC) * ((Hout + TP // PC - 1) // (TP // PC))
+    blocks = ((cin + 31) // 32) * ((cout + 63) // 64)
+    return max(1, min(ntiles, (4 * ctx.cus) // blocks))
+
+
+def _wgrad(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int, Wout: int, K: int, S: int, pad: int,
+           pad_mode: int, dst: Tensor, so: int, sc: int, taps: Sequence[int], accumulate: int,
+           valid: Optional[Tensor]) -> None:
+    s0 = srcs[0]
+    s1 = srcs[1] if len(srcs) > 1 else None
+    N, C0, Hin, Win = s0.shape
+    C1 = s1.shape[1] if s1 is not None else 0
+    d = WgradDesc(N, C0, C1, Hin, Win, Cout, Hout, Wout, K, K, S, pad, pad, pad_mode,
+                  _wgrad_slices(ctx, N, Hout, Wout, S, C0 + C1, Cout))
+    nfl = lib().c2s_wgrad_workspace_floats(C.byref(d))
+    slabs = ctx.ws.get("wgrad_slabs", nfl)
+    check(lib().c2s_conv_wgrad(C.byref(d), s0.data_ptr(), _ptr(s1), gout.data_ptr(), slabs.data_ptr(), slabs.numel(),
+                               _ptr(valid), _stream()), "conv_wgrad")
+    check(lib().c2s_wgrad_reduce(C.byref(d), slabs.data_ptr(), dst.data_ptr(), so, sc, _tap_array(taps), accumulate,
+                                 _stream()), "wgrad_reduce")
+
+
+def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K: int, S: int, pad: int,
+           pad_mode: int, valid: Optional[Tensor], need_input_grad: bool = True) -> Tensor:
+    """nn.Conv2d (reference conv.py:70-80, 263-271, 378-382) over the channel concatenation of `srcs`."""
+    W = ctx.p[wname]
+    Cout, Cin = W.shape[0], W.shape[1]
+    s0 = srcs[0]
+    s1 = srcs[1] if len(srcs) > 1 else None
+    N, C0, Hin, Win = s0.shape
+    C1 = s1.shape[1] if s1 is not None else 0
+    assert C0 + C1 == Cin, (wname, C0, C1, Cin)
+    Ho = (Hin + 2 * pad - K) // S + 1
+    Wo = (Win + 2 * pad - K) // S + 1
+    KK = K * K
+    wpk, CoutP = ctx.pack((wname, "fwd"), W, 0, Cin, Cout, KK, Cin * KK, KK, list(range(KK)))
+    out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
+    d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
+    _igemm(d, s0, s1, wpk, ctx.p[bname] if bname else None, out, valid)
+    if ctx.tape is None:
+        return out
+    tape = ctx.tape
+    tape.track(out)
+
+    def bwd():
+        g = tape.pop_grad(out)
+        if g is None:
+            return
+        gw, acc = ctx.grad_sink(wname)
+        _wgrad(ctx, srcs, g, Cout, Ho, Wo, K, S, pad, pad_mode, gw, Cin * KK, KK, list(range(KK)), acc, valid)
+        if not need_input_grad:
+            return
+        c_lo = 0
+        for si, src in enumerate(srcs):
+            Cs = src.shape[1]
+            existing = tape.grad_of(src)
+            gin = existing if existing is not None else torch.empty_like(src)
+            accf = 1 if existing is not None else 0
+            if S == 1:
+                taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
+                wd, CP = ctx.pack((wname, "dgrad", si), W, c_lo * KK, Cout, Cs, KK, KK, Cin * KK, taps)
+                dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, K - 1 - pad, K - 1 - pad,
+                              _lib.PAD_ZEROS, 1, 1, 0, 0, accf)
+                _igemm(dd, g, None, wd, None, gin, valid)
+            else:
+                assert K == 4 and S == 2 and pad == 1
+                for py in range(2):
+                    for px in range(2):
+                        taps = [((3 - py) - 2 * ty) * 4 + ((3 - px) - 2 * tx) for ty in range(2) for tx in range(2)]
+                        wd, CP = ctx.pack((wname, "dgrad", si, py, px), W, c_lo * KK, Cout, Cs, 4, KK, Cin * KK, taps)
+                        dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Ho, Wo, Hin, Win, 2, 2, 1, 1 - py, 1 - px,
+                                      _lib.PAD_ZEROS, 2, 2, py, px, accf)
+                        _igemm(dd, g, None, wd, None, gin, valid)
+            if pad_mode == _lib.PAD_REFLECT and pad > 0:
+                Wv = W if len(srcs) == 1 else W[:, c_lo:c_lo + Cs].contiguous()
+                check(lib().c2s_conv_reflect_dgrad_border(g.data_ptr(), Wv.data_ptr(), gin.data_ptr(), _ptr(valid), N, Cs,
+                                                          Cout, Hin, Win, K, S, _stream()), "reflect_border")
+            if existing is None:
+                tape.grads[src.data_ptr()] = gin
+            c_lo += Cs
+
+    tape.record(bwd)
+    return out
+
+
+def conv_transpose2d(ctx: Ctx, x: Tensor, wname: str, bname: str) -> Tensor:
+    """nn.ConvTranspose2d(k=4, s=2, p=1) (reference conv.py:384-390) as four 2x2 parity sub-convolutions."""
+    Wt = ctx.p[wname]
+    Cin, Cout = Wt.shape[0], Wt.shape[1]
+    N, _, H, Wd = x.shape
+    out = torch.empty(N, Cout, 2 * H, 2 * Wd, device=x.device, dtype=torch.float32)
+    bias = ctx.p[bname]
+    for py in range(2):
+        for px in range(2):
+            taps = [((3 - py) - 2 * ty) * 4 + ((3 - px) - 2 * tx) for ty in range(2) for tx in range(2)]
+            wpk, CP = ctx.pack((wname, "fwd", py, px), Wt, 0, Cin, Cout, 4, 16, Cout * 16, taps)
+            d = ConvDesc(N, Cin, 0, H, Wd, Cout, CP, H, Wd, 2 * H, 2 * Wd, 2, 2, 1, 1 - py, 1 - px, _lib.PAD_ZEROS,
+                         2, 2, py, px, 0)
+            _igemm(d, x, None, wpk, bias, out, None)
+    if ctx.tape is None:
+        return out
+    tape = ctx.tape
+    tape.track(out)
+
+    def bwd():
+        g = tape.pop_grad(out)
+        if g is None:
+            return
+        gw, acc = ctx.grad_sink(wname)
+        # dW[ci,co,k] = sum x[ci,p] * g[co, 2p+k-1]  ==  conv4x4s2 weight gradient with (input=g, gout=x)
+        _wgrad(ctx, [g], x, Cin, H, Wd, 4, 2, 1, _lib.PAD_ZEROS, gw, Cout * 16, 16, list(range(16)), acc, None)
+        existing = tape.grad_of(x)
+        gin = existing if existing is not None else torch.empty_like(x)
+        wd, CP = ctx.pack((wname, "dgrad"), Wt, 0, Cout, Cin, 16, Cout * 16, 16, list(range(16)))
+        dd = ConvDesc(N, Cout, 0, 2 * H, 2 * Wd, Cin, CP, H, Wd, H, Wd, 4, 4, 2, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
+                      1 if existing is not None else 0)
+        _igemm(dd, g, None, wd, None, gin, None)
+        if existing is None:
+            tape.grads[x.data_ptr()] = gin
+
+    tape.record(bwd)
+    return out
+
+
+def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, pad_mode: int,
+                     valid: Optional[Tensor]) -> Tensor:
+    """Depthwise part of DepthwiseSeparableConv2D (reference conv.py:18-20)."""
+    W = ctx.p[wname]
+    N, Cc, Hin, Win = x.shape
+    Ho = (Hin + 2 * pad - K) // S + 1
+    Wo = (Win + 2 * pad - K) // S + 1
+    out = torch.empty(N, Cc, Ho, Wo, device=x.device, dtype=torch.float32)
+    check(lib().c2s_dwconv_fwd(x.data_ptr(), W.data_ptr(), out.data_ptr(), _ptr(valid), N, Cc, Hin, Win, K, S, pad,
+                               pad_mode, _stream()), "dwconv_fwd")
+    if ctx.tape is None:
+        return out
+    tape = ctx.tape
+    tape.track(out)
+
+    def bwd():
+        g = tape.pop_grad(out)
+        if g is None:
+            return
+        gw, acc = ctx.grad_sink(wname)
+        part = ctx.ws.get("dw_partial", N * Cc * K * K)
+        tgt = gw if not acc else torch.empty_like(gw)
+        check(lib().c2s_dwconv_wgrad(x.data_ptr(), g.data_ptr(), part.data_ptr(), tgt.data_ptr(), _ptr(valid), N, Cc, Hin,
+                                     Win, K, S, pad, pad_mode, _stream()), "dwconv_wgrad")
+        if acc:
+            gw.add_(tgt)
+        gin = torch.empty_like(x)
+        check(lib().c2s_dwconv_dgrad(g.data_ptr(), W.data_ptr(), gin.data_ptr(), _ptr(valid), N, Cc, Hin, Win, K, S, pad,
+                                     pad_mode, _stream()), "dwconv_dgrad")
+        tape.add_grad(x, gin)
+
+    tape.record(bwd)
+    return out
+
+
+# =================================================================================================
+# normalisation (+ReLU, +residual)
+# =================================================================================================
+def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: bool, residual: Optional[Tensor],
+             valid: Optional[Tensor], pad_value: float = 0.0, conv_bias: Optional[str] = None) -> Tensor:
+    """GroupNorm / BatchNorm (+ReLU) (+ residual add) on NCHW x.  `conv_bias` names the bias of the convolution
+    that produced x: its gradient (= per-channel sum of dx) falls out of the same reduction."""
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    batch = kind == _lib.NORM_BATCH
+    training = 1 if (ctx.training or not batch) else 0
+    d = NormDesc(N, Cc, HW, kind, groups if not batch else 1, training if batch else 1, ctx.eps, ctx.momentum)
+    gamma, beta = ctx.p[prefix + ".weight"], ctx.p[prefix + ".bias"]
+    rm = ctx.b.get(prefix + ".running_mean") if batch else None
+    rv = ctx.b.get(prefix + ".running_var") if batch else None
+    ngroups = Cc if batch else N * groups
+    gstats = torch.empty(ngroups * 2, device=x.device, dtype=torch.float32)
+    row_ab = torch.empty(N * Cc * 2, device=x.device, dtype=torch.float32)
+    nws = lib().c2s_norm_workspace_floats(C.byref(d))
+    ws = ctx.ws.get("norm", nws)
+    check(lib().c2s_norm_stats(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
+                               gstats.data_ptr(), row_ab.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(valid), _stream()),
+          "norm_stats")
+    if batch and ctx.training:
+        nbt = ctx.b.get(prefix + ".num_batches_tracked")
+        if nbt is not None:
+            nbt.add_(1)
+    y = torch.empty_like(x)
+    check(lib().c2s_norm_apply(C.byref(d), x.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(), int(relu),
+                               _ptr(valid), float(pad_value), _stream()), "norm_apply")
+    if ctx.tape is None:
+        return y
+    tape = ctx.tape
+    tape.track(y)
+
+    def bwd():
+        g = tape.pop_grad(y)
+        if g is None:
+            return
+        if residual is not None:
+            tape.add_grad(residual, g, own=False)
+        gx = g  # in place
+        dgamma, _ = ctx.grad_sink(prefix + ".weight")
+        dbeta, _ = ctx.grad_sink(prefix + ".bias")
+        dbias = ctx.grad_sink(conv_bias)[0] if conv_bias else None
+        ws2 = ctx.ws.get("norm", nws)
+        check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
+                                 row_ab.data_ptr(), int(relu), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                 _ptr(dbias), ws2.data_ptr(), ws2.numel(), _ptr(valid), _stream()), "norm_bwd")
+        tape.add_grad(x, gx)
+
+    tape.record(bwd)
+    return y
+
+
+# =================================================================================================
+# temporal aggregation
+# =================================================================================================
+def temporal_aggregate(ctx: Ctx, x5: Tensor, attn: Tensor, valid: Optional[Tensor], n_head: int) -> Tensor:
+    """TemporalAggregator, mode att_group (reference temporal_aggregator.py:14-45,58-70)."""
+    B, T, Cc, H, W = x5.shape
+    h, w = attn.shape[-2:]
+    d = AggDesc(B, T, Cc, H, W, n_head, h, w)
+    out = torch.empty(B, Cc, H, W, device=x5.device, dtype=torch.float32)
+    check(lib().c2s_temporal_aggregate_fwd(C.byref(d), x5.data_ptr(), attn.data_ptr(), _ptr(valid), out.data_ptr(),
+                                           _stream()), "temporal_aggregate_fwd")
+    if ctx.tape is None:
+        return out
+    tape = ctx.tape
+    tape.track(out)
+
+    def bwd():
+        g = tape.pop_grad(out)
+        if g is None:
+            return
+        existing = tape.grad_of(x5)
+        gx = existing if existing is not None else torch.empty_like(x5)
+        gattn = tape.grad_of(attn)
+        if gattn is None:
+            gattn = torch.zeros_like(attn)
+            tape.grads[attn.data_ptr()] = gattn
+        nws = lib().c2s_temporal_aggregate_bwd_workspace_floats(C.byref(d))
+        ws = ctx.ws.get("agg", nws)
+        check(lib().c2s_temporal_aggregate_bwd(C.byref(d), x5.data_ptr(), attn.data_ptr(), _ptr(valid), g.data_ptr(),
+                                               gx.data_ptr(), 1 if existing is not None else 0, gattn.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), _stream()), "temporal_aggregate_bwd")
+        if existing is None:
+            tape.grads[x5.data_ptr()] = gx
+
+    tape.record(bwd)
+    return out
+
+
+# =================================================================================================
+# L-TAE
+# =================================================================================================
+def positional_table(dates: Tensor, d: int, period: float) -> Tensor:
+    """[B,T] int days -> [B,T,d] sinusoid table (reference positional_encoding.py:16-33); host-side table."""
+    i = torch.arange(d, device=dates.device, dtype=torch.float32)
+    denom = torch.pow(torch.tensor(period, device=dates.device, dtype=torch.float32),
+                      2 * torch.div(i, 2, rounding_mode="floor") / d)
+    tab = dates.to(torch.float32)[:, :, None] / denom[None, None, :]
+    out = torch.empty_like(tab)
+    out[..., 0::2] = torch.sin(tab[..., 0::2])
+    out[..., 1::2] = torch.cos(tab[..., 1::2])
+    return out
+
+
+def _fold_attention_params(Q: Tensor, Wk: Tensor, bk: Tensor, Wc: Tensor, bc: Tensor, pe: Tensor, n_head: int,
+                           d_k: int) -> Tuple[Tensor, Tensor]:
+    """Parameter-only folding: U [H,C] and s0 [B,T,H] such that
+    score[h,t] = U[h] . xhat_t + s0[b,t,h] equals q_h . (Wk_h (Wc xhat_t + bc + pe_t) + bk_h) / sqrt(d_k)."""
+    H = n_head
+    dm = Wk.shape[1]
+    scale = 1.0 / (d_k ** 0.5)
+    qWk = torch.einsum("hd,hdm->hm", Q[:, 0, :], Wk.view(H, d_k, dm)) * scale          # [H,dm]
+    U = qWk @ Wc                                                                      # [H,C]
+    pe_full = pe.repeat(1, 1, H)                                                      # [B,T,dm]
+    s0 = torch.einsum("hm,btm->bth", qWk, pe_full + bc[None, None, :])
+    s0 = s0 + (torch.einsum("hd,hd->h", Q[:, 0, :], bk.view(H, d_k)) * scale)[None, None, :]
+    return U.contiguous(), s0.contiguous()
+
+
+def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor], prefix: str, n_head: int, d_k: int,
+                   d_model: int, period: float, dropout_p: float, with_embedding: bool, seed: int,
+                   keep: Optional[Tensor]) -> Tuple[Optional[Tensor], Tensor]:
+    """L-TAE steps 1-6 (reference tae.py:451-481, 738-847).  Returns (emb [B,d_model,h,w] | None, attn [H,B,T,h,w])."""
+    B, T, Cc, h, w = x5.shape
+    HW = h * w
+    Q = ctx.p[prefix + ".attention_head.Q"]
+    Wk = ctx.p[prefix + ".attention_head.fc1_k.weight"]
+    bk = ctx.p[prefix + ".attention_head.fc1_k.bias"]
+    Wc3 = ctx.p[prefix + ".inconv.weight"]
+    bc = ctx.p[prefix + ".inconv.bias"]
+    gamma, beta = ctx.p[prefix + ".in_norm.weight"], ctx.p[prefix + ".in_norm.bias"]
+    pe = positional_table(dates, d_model // n_head, period).contiguous()
+    leaves = None
+    if ctx.tape is not None:
+        leaves = [t.detach().clone().requires_grad_(True) for t in (Q, Wk, bk, Wc3, bc)]
+        with torch.enable_grad():
+            U, s0 = _fold_attention_params(leaves[0], leaves[1], leaves[2], leaves[3][:, :, 0], leaves[4], pe, n_head, d_k)
+    else:
+        with torch.no_grad():
+            U, s0 = _fold_attention_params(Q, Wk, bk, Wc3[:, :, 0], bc, pe, n_head, d_k)
+    Wc = Wc3.view(d_model, Cc)
+    p_eff = dropout_p if ctx.training else 0.0
+    d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None)
+    attn = torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
+    attn_pre = torch.empty_like(attn) if ctx.tape is not None else None
+    emb = torch.empty(B, d_model, h, w, device=x5.device, dtype=torch.float32) if with_embedding else None
+    stats = torch.empty(B * HW * n_head * 2, device=x5.device, dtype=torch.float32)
+    Ud, s0d = U.detach(), s0.detach()
+    check(lib().c2s_ltae_attn_fwd(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
+                                  s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
+                                  attn.data_ptr(), _ptr(attn_pre), _ptr(emb), stats.data_ptr(), _stream()), "ltae_fwd")
+    if ctx.tape is None:
+        return emb, attn
+    tape = ctx.tape
+    tape.track(attn)
+    if emb is not None:
+        tape.track(emb)
+
+    def bwd():
+        g_attn = tape.pop_grad(attn)
+        g_emb = tape.pop_grad(emb) if emb is not None else None
+        if g_attn is None and g_emb is None:
+            return
+        gx = torch.empty_like(x5)
+        dev = x5.device
+        gU = torch.empty(n_head, Cc, device=dev)
+        gs0 = torch.empty(B, T, n_head, device=dev)
+        gWc = torch.empty(d_model, Cc, device=dev)
+        gbc = torch.empty(d_model, device=dev)
+        ggam, _ = ctx.grad_sink(prefix + ".in_norm.weight")
+        gbet, _ = ctx.grad_sink(prefix + ".in_norm.bias")
+        nws = lib().c2s_ltae_bwd_workspace_floats(C.byref(d))
+        ws = ctx.ws.get("ltae", nws)
+        check(lib().c2s_ltae_attn_bwd(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
+                                      s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
+                                      attn.data_ptr(), attn_pre.data_ptr(), stats.data_ptr(), _ptr(g_emb), _ptr(g_attn),
+                                      gx.data_ptr(), gU.data_ptr(), gs0.data_ptr(), gWc.data_ptr(), gbc.data_ptr(),
+                                      ggam.data_ptr(), gbet.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ltae_bwd")
+        # chain the folded parameters back to Q, fc1_k, inconv (tiny parameter-only tensors)
+        gl = torch.autograd.grad([U, s0], leaves, [gU, gs0], allow_unused=True)
+        names = [prefix + ".attention_head.Q", prefix + ".attention_head.fc1_k.weight",
+                 prefix + ".attention_head.fc1_k.bias", prefix + ".inconv.weight", prefix + ".inconv.bias"]
+        for nme, gg, leaf in zip(names, gl, leaves):
+            ctx.add_param_grad(nme, gg if gg is not None else torch.zeros_like(leaf))
+        if emb is not None:
+            ctx.add_param_grad(prefix + ".inconv.weight", gWc.view(d_model, Cc, 1))
+            ctx.add_param_grad(prefix + ".inconv.bias", gbc)
+        tape.add_grad(x5, gx)
+
+    tape.record(bwd)
+    return emb, attn
+
+
+def dropout_nchw(ctx: Ctx, x: Tensor, p: float, seed: int, keep: Optional[Tensor]) -> Tensor:
+    """nn.Dropout of the L-TAE MLP (reference tae.py:448); identity in eval mode."""
+    if not ctx.training or p <= 0.0:
+        return x
+    B, Cc = x.shape[:2]
+    HW = x[0, 0].numel()
+    y = torch.empty_like(x)
+    check(lib().c2s_dropout_nchw(x.data_ptr(), y.data_ptr(), B, Cc, HW, p, seed, _ptr(keep), _stream()), "dropout")
+    if ctx.tape is not None:
+        tape = ctx.tape
+        tape.track(y)
+
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is None:
+                return
+            gx = torch.empty_like(g)
+            check(lib().c2s_dropout_nchw(g.data_ptr(), gx.data_ptr(), B, Cc, HW, p, seed, _ptr(keep), _stream()),
+                  "dropout_bwd")
+            tape.add_grad(x, gx)
+
+        tape.record(bwd)
+    return y
+
+
+def pixel_group_norm(ctx: Ctx, x: Tensor, prefix: str, groups: int) -> Tensor:
+    """out_norm of L-TAE: GroupNorm over channel groups of each pixel (reference tae.py:437-440,488)."""
+    B, Cc = x.shape[:2]
+    HW = x[0, 0].numel()
+    gamma, beta = ctx.p[prefix + ".weight"], ctx.p[prefix + ".bias"]
+    y = torch.empty_like(x)
+    stats = torch.empty(B * groups * HW * 2, device=x.device, dtype=torch.float32)
+    check(lib().c2s_pixel_gn_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, Cc,
+                                 HW, groups, ctx.eps, _stream()), "pixel_gn_fwd")
+    if ctx.tape is not None:
+        tape = ctx.tape
+        tape.track(y)
+
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is None:
+                return
+            gx = torch.empty_like(x)
+            dg, _ = ctx.grad_sink(prefix + ".weight")
+            db, _ = ctx.grad_sink(prefix + ".bias")
+            nws = lib().c2s_pixel_gn_bwd_workspace_floats(B, Cc, HW)
+            ws = ctx.ws.get("pixel_gn", nws)
+            check(lib().c2s_pixel_gn_bwd(x.data_ptr(), g.data_ptr(), gamma.data_ptr(), stats.data_ptr(), gx.data_ptr(),
+                                         dg.data_ptr(), db.data_ptr(), B, Cc, HW, groups, ws.data_ptr(), ws.numel(),
+                                         _stream()), "pixel_gn_bwd")
+            tape.add_grad(x, gx)
+
+        tape.record(bwd)
+    return y
+
+
+# =================================================================================================
+# loss / optimiser
+# =================================================================================================
+def cross_entropy(logits: Tensor, target: Tensor, class_w: Tensor, ws: Workspace,
+                  want_grad: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """nn.CrossEntropyLoss(weight=class_w) (reference train.py:463-468).  Returns (loss[1], dlogits | None)."""
+    B, K = logits.shape[:2]
+    HW = logits[0, 0].numel()
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    gl = torch.empty_like(logits) if want_grad else None
+    n = lib().c2s_cross_entropy_workspace_floats(B, HW)
+    w = ws.get("ce", n)
+    check(lib().c2s_cross_entropy(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), loss.data_ptr(), _ptr(gl), B,
+                                  K, HW, w.data_ptr(), w.numel(), _stream()), "cross_entropy")
+    return loss, gl
+
+
+def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float = 1e-3, b1: float = 0.9,
+              b2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    check(lib().c2s_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps, step,
+                              grad_scale, _stream()), "adam")

@@ -1,0 +1,153 @@
+"""Harness pieces that sit directly on the hot path (reference src/learning/utils.py:50-136, 312-328;
+src/learning/weight_init.py:4-46; train.py:454,463-468): model selection, weight initialisation and the
+train step  zero_grad -> forward -> CrossEntropy -> backward -> (gradient all-reduce) -> Adam.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from .. import engine as E
+from ..backbones import functional as Fn
+from ..backbones.modules import UTAE, WTAE, TimeUNet_v1
+
+Tensor = torch.Tensor
+
+
+def get_model(config):
+    """reference src/learning/utils.py:50-136: dispatch on config.model with the same kwarg mapping
+    (encoder=False, return_maps=False fixed)."""
+    common = dict(
+        input_dim=config.input_dim, encoder_widths=config.encoder_widths, decoder_widths=config.decoder_widths,
+        out_conv=config.out_conv, str_conv_k=config.str_conv_k, str_conv_s=config.str_conv_s,
+        str_conv_p=config.str_conv_p, agg_mode=config.agg_mode, encoder_norm=config.encoder_norm, n_head=config.n_head,
+        d_model=config.d_model, d_k=config.d_k, encoder=False, return_maps=False, pad_value=config.pad_value,
+        padding_mode=config.padding_mode, conv_type=config.conv_type, use_mbconv=config.use_mbconv,
+        add_squeeze_excit=config.add_squeeze, use_abs_rel_enc=config.use_abs_rel_enc, num_queries=config.num_queries,
+        use_doy=config.use_doy, add_linear=config.add_linear)
+    if config.model == "utae":
+        return UTAE(add_boundary_loss=config.add_boundary_loss, **common)
+    if config.model == "wtae":
+        return WTAE(add_boundary_loss=config.add_boundary_loss, **common)
+    if config.model == "timeunet":
+        return TimeUNet_v1(**common)
+    raise NotImplementedError(f"model {config.model!r}: crop2seg_amd builds utae / wtae / timeunet")
+
+
+def default_config(model: str = "utae", **overrides):
+    """argparse defaults of the reference's train.py:25-186 that reach get_model()."""
+    from types import SimpleNamespace
+    cfg = dict(model=model, encoder_widths=[64, 64, 64, 128], decoder_widths=[32, 32, 64, 128], out_conv=[32, 15],
+               str_conv_k=4, str_conv_s=2, str_conv_p=1, agg_mode="att_group", encoder_norm="group", n_head=16,
+               d_model=256, d_k=4, input_dim=10, num_queries=1, pad_value=0, padding_mode="reflect", conv_type="2d",
+               use_mbconv=False, add_squeeze=False, use_doy=False, use_abs_rel_enc=False, add_linear=False,
+               add_boundary_loss=False, num_classes=15, ignore_index=-1, lr=1e-3, label_smoothing=0.0)
+    cfg.update(overrides)
+    return SimpleNamespace(**cfg)
+
+
+def weight_init(m):
+    """reference src/learning/weight_init.py:4-46 (the module types that occur in the three backbones)."""
+    if isinstance(m, nn.Conv1d):
+        init.normal_(m.weight.data)
+        if m.bias is not None:
+            init.normal_(m.bias.data)
+    elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        init.xavier_normal_(m.weight.data)
+        if m.bias is not None:
+            init.normal_(m.bias.data)
+    elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+        init.normal_(m.weight.data, mean=0, std=1)
+        init.constant_(m.bias.data, 0)
+    elif isinstance(m, nn.Linear):
+        init.xavier_normal_(m.weight.data)
+        if m.bias is not None:
+            init.normal_(m.bias.data)
+
+
+class TrainStep:
+    """One optimiser step of the reference's training loop (src/learning/utils.py:314-328) with everything on
+    the HIP engine and no autograd graph:
+
+        zero_grad -> model(x, batch_positions=dates) -> CrossEntropyLoss(weight) -> backward -> Adam.step()
+
+    Parameters, gradients and Adam moments live in three flat fp32 buffers (the module's parameters are
+    re-pointed at views of the flat parameter buffer), so data-parallel training needs exactly one all-reduce of
+    `flat_grad` per step (RCCL over xGMI; torch.distributed backend "nccl") and the optimiser is one kernel.
+    """
+
+    def __init__(self, model, num_classes: int = 15, ignore_index: int = -1, lr: float = 1e-3,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, process_group=None,
+                 distributed: bool = False):
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        named = list(model.named_parameters())
+        self.names = [n for n, _ in named]
+        dev = named[0][1].device
+        sizes = [p.numel() for _, p in named]
+        # 16-byte aligned slots
+        offs, o = [], 0
+        for s in sizes:
+            offs.append(o)
+            o += (s + 3) // 4 * 4
+        self.total = o
+        self.flat_param = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.params: Dict[str, Tensor] = {}
+        self.grads: Dict[str, Tensor] = {}
+        for (n, p), off, s in zip(named, offs, sizes):
+            view = self.flat_param[off:off + s].view_as(p)
+            view.copy_(p.data)
+            p.data = view                               # module parameters now alias the flat buffer
+            self.params[n] = view
+            self.grads[n] = self.flat_grad[off:off + s].view_as(p)
+        cw = torch.ones(num_classes, device=dev, dtype=torch.float32)
+        cw[ignore_index] = 0                            # train.py:463-464
+        self.class_w = cw
+        self.step_count = 0
+        self.ws = E.Workspace(dev)
+        self.distributed = distributed
+        self.group = process_group
+        self.world = 1
+        if distributed:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            dist.broadcast(self.flat_param, src=0, group=process_group)   # identical initial weights on every rank
+
+    @torch.no_grad()
+    def __call__(self, x: Tensor, dates: Tensor, y: Tensor, dropout_state: Optional[Fn.DropoutState] = None,
+                 apply_update: bool = True) -> Tuple[Tensor, Tensor]:
+        """Returns (loss[1] device tensor, logits).  No host synchronisation inside."""
+        model = self.model
+        model._check_inputs(x, dates)
+        drop = dropout_state
+        if drop is None:
+            drop = Fn.DropoutState()
+            if model.training:
+                self.step_count_seed = getattr(self, "step_count_seed", 0) + 1
+                base = (torch.initial_seed() * 0x9E3779B1 + self.step_count_seed * 2) & ((1 << 62) - 1)
+                drop.attn_seed, drop.mlp_seed = base, base + 1
+        tape = E.Tape()
+        ctx = E.Ctx(self.params, dict(model.named_buffers()), self.grads, self.ws, model.training, tape)
+        logits, _att = Fn.FORWARDS[model.spec.model](ctx, model.spec, x.contiguous(), dates.contiguous(), drop)
+        loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True)
+        tape.grads[logits.data_ptr()] = glogits
+        tape.backward()
+        for n in self.names:                             # parameters no kernel wrote to (none in the default models)
+            if n not in ctx._gwritten:
+                self.grads[n].zero_()
+        scale = 1.0
+        if self.distributed and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, group=self.group)             # one 4.3 MB bucket per step
+            scale = 1.0 / self.world
+        if apply_update:
+            self.step_count += 1
+            E.adam_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                        self.betas[0], self.betas[1], self.eps, grad_scale=scale)
+        return loss, logits

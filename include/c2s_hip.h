@@ -1,0 +1,241 @@
+/* c2s_hip.h -- C ABI of libc2s_hip.so: MI355X (gfx950) kernels for the Crop2Seg backbone hot path
+ * (U-TAE / TimeUNet_v1 / W-TAE forward + backward).
+ *
+ * The reference (Many98/Crop2Seg) has no FFI / plugin layer: its hot path is stock ATen ops called
+ * from nn.Module.forward.  Each entry point below therefore cites the reference
+ * *call site* (file:line under the reference root) whose ATen op(s) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()) unless named host_*; tensors are dense fp32,
+ *     NCHW with the (batch, time) axes folded into N = B*T "frames" where the reference folds them
+ *     (src/backbones/temp_shared_block.py:28);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - entry points never allocate, never synchronise and never throw: they validate their arguments,
+ *     enqueue kernels on `stream` and return C2S_OK or a negative C2S_E* code, so a sequence of calls
+ *     is hipGraph-capturable; scratch memory is caller-provided (query with the *_workspace_floats calls);
+ *   - `valid` is an int32[N] per-frame flag array (1 = real frame, 0 = temporal padding) or NULL when
+ *     every frame is real; padded frames are skipped (reference: temp_shared_block.py:31-40).
+ */
+#ifndef C2S_HIP_H
+#define C2S_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2S_OK 0
+#define C2S_EINVAL (-1)   /* bad shape / unsupported configuration */
+#define C2S_ELAUNCH (-2)  /* hipLaunch error (see c2s_last_error) */
+#define C2S_ENOSPACE (-3) /* workspace too small */
+
+#define C2S_PAD_ZEROS 0
+#define C2S_PAD_REFLECT 1
+
+#define C2S_NORM_GROUP 0 /* statistics over (frame, channel group) : nn.GroupNorm */
+#define C2S_NORM_BATCH 1 /* statistics over (all frames, channel)  : nn.BatchNorm2d / BatchNorm1d (train) */
+
+int c2s_abi_version(void);
+const char* c2s_last_error(void);
+/* number of compute units of the current device (for split-K sizing); <=0 on error */
+int c2s_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing.  The implicit-GEMM kernels read weights as wpk[tap][cin][coutP] (coutP = cout rounded
+ * up to 32, zero filled).  A "tap table" selects and orders the (ky,kx) taps of the source kernel, so one
+ * pack kernel serves: Conv2d forward (conv.py:70-80), its data gradient (flipped taps, cin<->cout
+ * swapped), ConvTranspose2d (conv.py:384-390) as four 2x2 parity sub-kernels, and their data gradients.
+ *   src element (o, c, t) is read at  src[o*stride_o + c*stride_c + tap_off[t]].
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_pack_weights(const float* src, float* wpk, int cin, int cout, int coutP, int ntaps,
+                     long stride_o, long stride_c, const int* host_tap_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on f32 MFMA (v_mfma_f32_32x32x2_f32), forward and data-gradient.
+ *   out[n, o, oy*osy+ooy, ox*osx+oox] (+)= bias[o] + sum_{c,ky,kx} in[n, c, map(oy*S+ky-pad_y), map(ox*S+kx-pad_x)]
+ *                                                               * wpk[ky*KW+kx][c][o]
+ * `in` is the channel concatenation of src0 (C0 channels) and src1 (C1 channels; may be NULL/0): the
+ * torch.cat of conv.py:408 is never materialised.  map() = zero padding or reflection (conv.py:72-79).
+ * Replaces: nn.Conv2d 3x3 / 4x4-stride-2 / 1x1 (conv.py:70-80,263-271,378-382), nn.ConvTranspose2d
+ * (conv.py:384-390; four launches, one per output parity) and every convolution_backward-input.
+ * Supported (KH,KW,S): (3,3,1) (1,1,1) (2,2,1) (4,4,2).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct c2s_conv_desc {
+    int N, C0, C1;        /* frames; channels of src0 / src1 */
+    int Hin, Win;         /* input plane */
+    int Cout, CoutP;      /* real / packed output channels */
+    int Hout, Wout;       /* logical output grid computed by this launch */
+    int OutH, OutW;       /* physical output plane (>= grid*stride+offset) */
+    int KH, KW, S;        /* kernel, input stride */
+    int pad_y, pad_x;
+    int pad_mode;         /* C2S_PAD_* */
+    int osy, osx, ooy, oox; /* output placement stride / offset */
+    int accumulate;       /* 0: out = r ; 1: out += r */
+} c2s_conv_desc;
+
+int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const float* src1, const float* wpk,
+                   const float* bias, float* out, const int* valid, void* stream);
+
+/* Border terms of the data gradient of a reflect-padded convolution (adjoint of reflection: the halo
+ * gradient folds back onto rows/cols 1 and H-2 / W-2).  Call after the zero-padded c2s_conv_igemm data
+ * gradient; adds into gin.  w is the *forward* weight in torch layout [Cout,Cin,KH,KW].
+ * Replaces the reflection_pad2d_backward of conv.py:72-79.  Supported (K,S): (3,1), (4,2). */
+int c2s_conv_reflect_dgrad_border(const float* gout, const float* w, float* gin, const int* valid,
+                                  int N, int Cin, int Cout, int Hin, int Win, int K, int S, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient (convolution_backward-weight of the same call sites), split-K over output tiles:
+ *   slab[s][t][c][o] = sum over the tiles of slice s of  in[n,c,map(oy*S+ky-pad),..] * gout[n,o,oy,ox]
+ * followed by c2s_wgrad_reduce which sums the slices (fixed order: bitwise reproducible) and scatters to
+ * the destination layout  dst[o*stride_o + c*stride_c + tap_off[t]] (+)= .
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct c2s_wgrad_desc {
+    int N, C0, C1, Hin, Win;
+    int Cout;
+    int Hout, Wout;       /* gout plane */
+    int KH, KW, S, pad_y, pad_x, pad_mode;
+    int nslices;
+} c2s_wgrad_desc;
+
+size_t c2s_wgrad_workspace_floats(const c2s_wgrad_desc* d);
+int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const float* src1, const float* gout,
+                   float* slabs, size_t slab_floats, const int* valid, void* stream);
+int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, float* dst, long stride_o, long stride_c,
+                     const int* host_tap_off, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise convolution (groups = C, no bias) forward / data gradient / weight gradient.
+ * Replaces DepthwiseSeparableConv2D.depthwise (conv.py:18-20,24), used by W-TAE (wtae.py:148-162).
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_dwconv_fwd(const float* in, const float* w, float* out, const int* valid, int N, int C, int Hin, int Win,
+                   int K, int S, int pad, int pad_mode, void* stream);
+int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, const int* valid, int N, int C, int Hin, int Win,
+                     int K, int S, int pad, int pad_mode, void* stream);
+/* gw[C,K,K] = sum_n ...; `partial` is scratch of N*C*K*K floats */
+int c2s_dwconv_wgrad(const float* in, const float* gout, float* partial, float* gw, const int* valid, int N, int C,
+                     int Hin, int Win, int K, int S, int pad, int pad_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation + ReLU (+ residual), GroupNorm and train/eval BatchNorm share one set of kernels:
+ *   rows = (frame n, channel c), each row = HW contiguous floats.
+ *   c2s_norm_stats   : per-(row,segment) mean / M2 (two-pass, wave per segment) -> finalised per group
+ *                      into per-row scale/shift  a[n,c], b[n,c]  (y = a*x + b), plus mean/rstd per group.
+ *   c2s_norm_apply   : y = relu(a*x+b) (+ residual); rows of padded frames are filled with pad_value.
+ *   c2s_norm_bwd     : given g = dL/dy: (1) per-row sums of g' = g*[y>0] and g'*xhat, (2) finalise:
+ *                      dgamma, dbeta, dbias (gradient of the bias of the producing convolution) and the
+ *                      per-row coefficients of  dx = k1*g' + k2*x + k3 , (3) elementwise dx.
+ * Replaces nn.GroupNorm(4) + ReLU (conv.py:56-60,85-88), nn.BatchNorm2d + ReLU (conv.py:52-53,380,388),
+ * the residual add of conv.py:292,410 and their backward ops.
+ * stats layout: group stats [G2][2] = (mean, rstd), G2 = N*groups (GROUP) or C (BATCH).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct c2s_norm_desc {
+    int N, C, HW;
+    int kind;             /* C2S_NORM_* */
+    int groups;           /* GROUP: channel groups per frame */
+    int training;         /* BATCH: 1 = batch statistics (+ running update), 0 = running statistics */
+    float eps, momentum;
+} c2s_norm_desc;
+
+size_t c2s_norm_workspace_floats(const c2s_norm_desc* d);
+/* running_mean/var: BATCH only (may be NULL for GROUP); updated in place when training */
+int c2s_norm_stats(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* group_stats, float* row_ab,
+                   float* workspace, size_t ws_floats, const int* valid, void* stream);
+int c2s_norm_apply(const c2s_norm_desc* d, const float* x, const float* row_ab, const float* residual,
+                   float* y, int relu, const int* valid, float pad_value, void* stream);
+/* gx may alias g.  dbias may be NULL.  g_residual_out: if non-NULL receives a copy of g (residual branch) */
+int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float* g, const float* gamma,
+                 const float* group_stats, const float* row_ab, int relu, float* gx, float* dgamma,
+                 float* dbeta, float* dbias, float* workspace, size_t ws_floats, const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frame flags: valid[n] = any(x[n] != pad_value)   (utae.py:201-203, temp_shared_block.py:31)
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_frame_flags(const float* x, int* valid, int N, long frame_elems, float pad_value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * L-TAE attention (tae.py:451-481 + 738-847), fused and re-associated:
+ *   per-pixel GroupNorm(16 groups over C/16 channels x T, padded frames included, tae.py:461),
+ *   folded key projection  score[h,t] = U[h,:].xhat_t + s0[b,t,h]   (U = q_h^T Wk_h Wc / sqrt(d_k) [16,C];
+ *   s0 [B,T,16] from the biases + positional table; both folded by the host from the parameters),
+ *   -1e6 masking of padded frames (tae.py:831), softmax over T, optional dropout (counter-based RNG or an
+ *   explicit keep mask [16,P,T]; the attention output is post-dropout, tae.py:836-847),
+ *   z[h,:] = sum_t attn[h,t] xhat_t  and  emb[16h+j] = Wc[16h+j,:].z[h,:] + (sum_t attn) bc + sum_t attn pe_t.
+ * Everything stays NCHW (pixel index fastest): x [B,T,C,hw]; attn, attn_pre [16,B,T,hw]; emb [B,256,hw]
+ * (NULL for W-TAE's attention-only variant, tae.py:619); stats [P,16,2] = (mean, rstd); pe [B,T,16].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct c2s_ltae_desc {
+    int B, T, C, HW;      /* HW = h*w pixels per frame at the L-TAE resolution (multiple of 16) */
+    int n_head, d_model;  /* built for 16 / 256 */
+    float eps;
+    float dropout_p;      /* 0 => no dropout */
+    uint64_t seed;        /* dropout RNG key */
+    const float* keep;    /* optional explicit keep mask [16,P,T] (tests); NULL => RNG when dropout_p>0 */
+} c2s_ltae_desc;
+
+int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                      const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                      const int* valid, float* attn, float* attn_pre, float* emb, float* stats, void* stream);
+size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
+/* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],
+ * gU [16,C], gs0 [B,T,16], gWc [256,C] (embedding path only), gbc [256], ggamma [C], gbeta [C]. */
+int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                      const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                      const int* valid, const float* attn, const float* attn_pre, const float* stats,
+                      const float* g_emb, const float* g_attn, float* gx, float* gU, float* gs0, float* gWc,
+                      float* gbc, float* ggamma, float* gbeta, float* workspace, size_t ws_floats, void* stream);
+
+/* L-TAE tail (tae.py:442-449,486-488).  Linear(256,C') is a 1x1 convolution on the NCHW embedding
+ * (c2s_conv_igemm), BatchNorm1d over P is c2s_norm_* with kind BATCH; the two pieces below are the rest:
+ * Dropout(0.2) with the keep mask indexed pixel-major [P,C] like the reference's activations, and the
+ * per-pixel GroupNorm(16) over channel groups (out_norm). */
+int c2s_dropout_nchw(const float* x, float* y, int B, int C, int HW, float p, uint64_t seed, const float* keep,
+                     void* stream);
+int c2s_pixel_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B, int C,
+                     int HW, int groups, float eps, void* stream);
+size_t c2s_pixel_gn_bwd_workspace_floats(int B, int C, int HW);
+int c2s_pixel_gn_bwd(const float* x, const float* gy, const float* gamma, const float* stats, float* gx,
+                     float* dgamma, float* dbeta, int B, int C, int HW, int groups, float* workspace,
+                     size_t ws_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal aggregation of skip features (temporal_aggregator.py:14-45,58-70, mode att_group):
+ *   out[b,c,Y,X] = sum_t valid[b,t] * bilinear_up(attn[g(c),b,t])(Y,X) * x[b,t,c,Y,X]
+ * bilinear align_corners=False (temporal_aggregator.py:17-19); g(c) = c / (C/n_head).
+ * Backward: gx[b,t,c] = up(attn)*gout ; gattn (low resolution, adjoint of the upsample) is ACCUMULATED
+ * into gattn (caller zeroes it once; U-TAE sums three resolutions into it).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct c2s_agg_desc {
+    int B, T, C, H, W;    /* feature maps x [B,T,C,H,W] */
+    int n_head, h, w;     /* attention maps [n_head,B,T,h,w] */
+} c2s_agg_desc;
+
+int c2s_temporal_aggregate_fwd(const c2s_agg_desc* d, const float* x, const float* attn, const int* valid,
+                               float* out, void* stream);
+size_t c2s_temporal_aggregate_bwd_workspace_floats(const c2s_agg_desc* d);
+int c2s_temporal_aggregate_bwd(const c2s_agg_desc* d, const float* x, const float* attn, const int* valid,
+                               const float* gout, float* gx, int gx_accumulate, float* gattn,
+                               float* workspace, size_t ws_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss + optimiser of the train step (train.py:454,463-468; src/learning/utils.py:314-328).
+ *   c2s_cross_entropy: weighted-mean CE with class weights w[K]; writes loss (1 float) and, if glogits
+ *   != NULL, dL/dlogits.  workspace 2*blocks floats (see query).
+ *   c2s_adam_flat: torch.optim.Adam defaults on a flat parameter buffer.
+ * ------------------------------------------------------------------------------------------------ */
+size_t c2s_cross_entropy_workspace_floats(int B, int HW);
+int c2s_cross_entropy(const float* logits, const int64_t* target, const float* class_w, float* loss,
+                      float* glogits, int B, int K, int HW, float* workspace, size_t ws_floats, void* stream);
+int c2s_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                  int step, float grad_scale, void* stream);
+
+/* elementwise helpers */
+int c2s_fill(float* p, long n, float v, void* stream);
+int c2s_add_inplace(float* dst, const float* src, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C2S_HIP_H */

@@ -1,0 +1,91 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol the header
+declares; the model classes reproduce the reference's state_dict layout; the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "c2s_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(c2s_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from crop2seg_amd import _lib, build
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/c2s_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes binding and header disagree"
+    assert _lib.lib().c2s_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate before touching the device: bad descriptors return C2S_EINVAL with a message."""
+    from crop2seg_amd import _lib
+    L = _lib.lib()
+    d = _lib.ConvDesc(1, 8, 0, 8, 8, 8, 30, 8, 8, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0)   # CoutP not a multiple of 32
+    rc = L.c2s_conv_igemm(ctypes.byref(d), 16, None, 16, None, 16, None, None)
+    assert rc == -1 and b"CoutP" in L.c2s_last_error()
+    nd = _lib.NormDesc(2, 10, 64, 0, 4, 1, 1e-5, 0.1)                                       # 10 % 4 != 0
+    assert L.c2s_norm_apply(ctypes.byref(nd), 16, 16, None, 16, 1, None, 0.0, None) == -1
+
+
+@pytest.mark.parametrize("name", ["utae_eval_pad_wi", "timeunet_eval_pad_wi", "wtae_eval_pad_wi"])
+def test_state_dict_layout_matches_reference(goldens, name):
+    import crop2seg_amd as C2S
+    g = goldens(name)
+    cls = {"utae": C2S.UTAE, "timeunet": C2S.TimeUNet_v1, "wtae": C2S.WTAE}[g.cfg.model]
+    net = cls(input_dim=10, out_conv=[32, 15])
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == g.key_shapes
+    net.load_state_dict(g.sd)     # strict
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == {"utae": 1085805, "timeunet": 1052589, "wtae": 1114157}[g.cfg.model]
+
+
+def test_weight_init_dispatch_matches_reference_types():
+    import crop2seg_amd as C2S
+    torch.manual_seed(0)
+    net = C2S.UTAE(input_dim=10, out_conv=[32, 15])
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    net.apply(C2S.weight_init)
+    after = net.state_dict()
+    changed = {k for k in after if after[k].dtype.is_floating_point and not torch.equal(after[k], before[k])}
+    # GroupNorm affine and Q are untouched by weight_init (reference weight_init.py has no branch for them)
+    assert "temporal_encoder.attention_head.Q" not in changed
+    assert "in_conv.conv.conv.1.weight" not in changed
+    assert "in_conv.conv.conv.0.weight" in changed and "up_blocks.0.up.0.weight" in changed
+    assert "temporal_encoder.mlp.2.weight" in changed and "temporal_encoder.inconv.bias" in changed
+
+
+def test_no_cpu_fallback():
+    import crop2seg_amd as C2S
+    net = C2S.UTAE(input_dim=10, out_conv=[32, 15])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 2, 10, 32, 32), batch_positions=torch.zeros(1, 2, dtype=torch.long))
+
+
+def test_offdefault_flags_fail_loudly():
+    import crop2seg_amd as C2S
+    with pytest.raises(NotImplementedError):
+        C2S.UTAE(input_dim=10, use_mbconv=True)
+    with pytest.raises(NotImplementedError):
+        C2S.WTAE(input_dim=10, agg_mode="mean")
+
+
+def test_get_model_mapping():
+    from crop2seg_amd.learning.utils import default_config, get_model
+    import crop2seg_amd as C2S
+    assert isinstance(get_model(default_config("utae")), C2S.UTAE)
+    assert isinstance(get_model(default_config("wtae")), C2S.WTAE)
+    assert isinstance(get_model(default_config("timeunet")), C2S.TimeUNet_v1)
+    m = get_model(default_config("utae"))
+    assert m.spec.out_conv == [32, 15] and m.spec.padding_mode == "reflect"

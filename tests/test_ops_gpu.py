@@ -1,0 +1,332 @@
+"""GPU parity tests of the individual HIP ops (through the C ABI) against the CPU oracle
+(oracle/crop2seg_oracle.py restatements + torch CPU autograd on them).  Tolerances: fp32 kernels vs an fp32 (or
+fp64) CPU evaluation of the same formula; the north star's bar is 1e-3 relative, the kernels are held to 1e-4..1e-5
+unless stated."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import crop2seg_oracle as O  # noqa: E402
+
+
+def _engine():
+    from crop2seg_amd import engine as E
+    from crop2seg_amd import _lib
+    return E, _lib
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_ctx(params, buffers=None, training=True, tape=True):
+    E, _ = _engine()
+    dev = torch.device("cuda")
+    p = {k: v.to(dev).contiguous() for k, v in params.items()}
+    b = {k: v.to(dev).contiguous() for k, v in (buffers or {}).items()}
+    g = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    return E.Ctx(p, b, g, E.Workspace(dev), training, E.Tape() if tape else None)
+
+
+def seed_backward(ctx, out, gout):
+    ctx.tape.grads[out.data_ptr()] = gout.to(out.device).contiguous().clone()
+    ctx.tape.backward()
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, K, S, pad, mode
+    (3, 10, 64, 32, 32, 3, 1, 1, "reflect"),
+    (2, 64, 64, 128, 128, 3, 1, 1, "reflect"),
+    (2, 64, 128, 16, 16, 3, 1, 1, "reflect"),
+    (2, 32, 15, 32, 32, 3, 1, 1, "reflect"),
+    (3, 64, 64, 8, 8, 3, 1, 1, "reflect"),
+    (2, 128, 128, 4, 4, 3, 1, 1, "reflect"),
+    (2, 64, 64, 64, 64, 4, 2, 1, "reflect"),
+    (3, 64, 64, 8, 8, 4, 2, 1, "reflect"),
+    (2, 64, 64, 32, 32, 1, 1, 0, "zeros"),
+    (2, 256, 128, 4, 4, 1, 1, 0, "zeros"),
+    (1, 24, 40, 24, 40, 3, 1, 1, "reflect"),      # ragged: sizes that are not powers of two
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case):
+    E, L = _engine()
+    N, Cin, Cout, H, W, K, S, pad, mode = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) / math.sqrt(Cin * K * K)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    valid = torch.ones(N, dtype=torch.int32)
+    if N >= 3:
+        valid[1] = 0
+    keep = valid.bool()
+    ref = O.conv2d(x[keep], w, b, S, pad, mode)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+
+    ctx = make_ctx({"w": w.detach(), "b": b.detach()})
+    xd = x.detach().cuda()
+    vd = valid.cuda()
+    out = E.conv2d(ctx, [xd], "w", "b", K, S, pad, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZEROS, vd)
+    assert rel(out[keep.cuda()], ref) < 2e-6
+    gfull = torch.zeros(N, *ref.shape[1:])
+    gfull[keep] = gout
+    seed_backward(ctx, out, gfull)
+    gx = ctx.tape.grads[xd.data_ptr()]
+    assert rel(gx[keep.cuda()], x.grad[keep]) < 5e-6
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 4, 4), (2, 64, 32, 16, 16), (1, 32, 32, 64, 64)])
+def test_conv_transpose_fwd_bwd(shape):
+    E, L = _engine()
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cin, Cout, 4, 4, generator=g) / math.sqrt(Cin * 4)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    ref = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({"w": w.detach(), "b": b.detach()})
+    xd = x.detach().cuda()
+    out = E.conv_transpose2d(ctx, xd, "w", "b")
+    assert rel(out, ref) < 2e-6
+    seed_backward(ctx, out, gout)
+    assert rel(ctx.tape.grads[xd.data_ptr()], x.grad) < 5e-6
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+
+
+def test_conv_concat_sources():
+    """conv1 of UpConvBlock reads [up, skip] without materialising torch.cat (reference conv.py:408)."""
+    E, L = _engine()
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(2, 32, 32, 32, generator=g, requires_grad=True)
+    s = torch.randn(2, 64, 32, 32, generator=g, requires_grad=True)
+    w = (torch.randn(32, 96, 3, 3, generator=g) / 30).requires_grad_(True)
+    b = torch.randn(32, generator=g, requires_grad=True)
+    ref = O.conv2d(torch.cat([a, s], 1), w, b, 1, 1, "reflect")
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({"w": w.detach(), "b": b.detach()})
+    ad, sd = a.detach().cuda(), s.detach().cuda()
+    out = E.conv2d(ctx, [ad, sd], "w", "b", 3, 1, 1, L.PAD_REFLECT, None)
+    assert rel(out, ref) < 2e-6
+    seed_backward(ctx, out, gout)
+    assert rel(ctx.tape.grads[ad.data_ptr()], a.grad) < 5e-6
+    assert rel(ctx.tape.grads[sd.data_ptr()], s.grad) < 5e-6
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+
+
+@pytest.mark.parametrize("K,S", [(3, 1), (4, 2)])
+def test_depthwise_fwd_bwd(K, S):
+    E, L = _engine()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 64, 16, 16, generator=g, requires_grad=True)
+    w = torch.randn(64, 1, K, K, generator=g, requires_grad=True)
+    ref = O.conv2d(x, w, None, S, 1, "reflect", groups=64)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({"w": w.detach()})
+    xd = x.detach().cuda()
+    out = E.depthwise_conv2d(ctx, xd, "w", K, S, 1, L.PAD_REFLECT, None)
+    assert rel(out, ref) < 2e-6
+    seed_backward(ctx, out, gout)
+    assert rel(ctx.tape.grads[xd.data_ptr()], x.grad) < 5e-6
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+
+
+@pytest.mark.parametrize("kind,shape,use_res,use_valid", [
+    ("group", (4, 64, 32, 32), False, True),
+    ("group", (3, 128, 4, 4), True, False),
+    ("group", (2, 64, 128, 128), True, True),
+    ("batch", (4, 32, 16, 16), False, False),
+    ("batch", (2, 15, 64, 64), True, False),
+])
+def test_norm_relu_fwd_bwd(kind, shape, use_res, use_valid):
+    E, L = _engine()
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    res = torch.randn(shape, generator=g, requires_grad=True) if use_res else None
+    valid = torch.ones(N, dtype=torch.int32)
+    if use_valid:
+        valid[0] = 0
+    keep = valid.bool()
+    rm, rv = torch.zeros(C), torch.ones(C)
+    if kind == "group":
+        y = F.relu(F.group_norm(x[keep], 4, gamma, beta, 1e-5))
+    else:
+        rm2, rv2 = rm.clone(), rv.clone()
+        y = F.relu(F.batch_norm(x[keep], rm2, rv2, gamma, beta, True, 0.1, 1e-5))
+    if use_res:
+        y = y + res[keep]
+    gout = torch.randn(y.shape, generator=g)
+    y.backward(gout)
+    ctx = make_ctx({"n.weight": gamma.detach(), "n.bias": beta.detach(), "cb": torch.zeros(C)},
+                   {"n.running_mean": rm, "n.running_var": rv, "n.num_batches_tracked": torch.zeros((), dtype=torch.int64)})
+    xd = x.detach().cuda()
+    rd = res.detach().cuda() if use_res else None
+    vd = valid.cuda() if use_valid else None
+    out = E.norm_act(ctx, xd, "n", L.NORM_GROUP if kind == "group" else L.NORM_BATCH, 4, True, rd, vd, 0.0, conv_bias="cb")
+    assert rel(out[keep.cuda()], y) < 2e-6
+    if use_valid:
+        assert float(out[0].abs().max()) == 0.0
+    if kind == "batch":
+        assert rel(ctx.b["n.running_mean"], rm2) < 1e-5 and rel(ctx.b["n.running_var"], rv2) < 1e-5
+    gfull = torch.zeros(shape)
+    gfull[keep] = gout
+    seed_backward(ctx, out, gfull)
+    gx = ctx.tape.grads[xd.data_ptr()]
+    tol = 2e-5
+    assert rel(gx[keep.cuda()], x.grad[keep]) < tol
+    assert rel(ctx.g["n.weight"], gamma.grad) < tol
+    assert rel(ctx.g["n.bias"], beta.grad) < tol
+    # gradient of the producing convolution's bias == per-channel sum of dx
+    assert rel(ctx.g["cb"], x.grad[keep].sum(dim=(0, 2, 3))) < 1e-4 or float(ctx.g["cb"].abs().max()) < 1e-4
+    if use_res:
+        assert rel(ctx.tape.grads[rd.data_ptr()][keep.cuda()], res.grad[keep]) < 1e-6
+
+
+def _ltae_state(C, g, flavour="tame"):
+    from oracle import seeded
+    ks = [("te.inconv.weight", (256, C, 1)), ("te.inconv.bias", (256,)), ("te.attention_head.Q", (16, 1, 4)),
+          ("te.attention_head.fc1_k.weight", (64, 256)), ("te.attention_head.fc1_k.bias", (64,)),
+          ("te.in_norm.weight", (C,)), ("te.in_norm.bias", (C,))]
+    return seeded.make_state(ks, 21, flavour)
+
+
+@pytest.mark.parametrize("B,T,C,h,with_emb,pad,drop", [
+    (2, 6, 128, 4, True, True, False),
+    (1, 5, 64, 8, True, False, True),
+    (2, 7, 128, 4, False, True, True),
+    (1, 61, 64, 16, True, True, False),     # TimeUNet-like: T = 61
+])
+def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
+    E, L = _engine()
+    g = torch.Generator().manual_seed(13)
+    sd = _ltae_state(C, g)
+    cfg = O.BackboneConfig()
+    x = torch.randn(B, T, C, h, h, generator=g)
+    dates = (5 * torch.arange(T)[None] + torch.arange(B)[:, None]).long()
+    valid = torch.ones(B, T, dtype=torch.int32)
+    if pad:
+        valid[0, T - 2:] = 0
+        x[0, T - 2:] = 0
+        dates[0, T - 2:] = 0
+    P = B * h * h
+    keep = (torch.rand(16, P, T, generator=g) >= 0.1).float() if drop else None
+    x.requires_grad_(True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    emb, attn = O.ltae_attention(x, dates, ~valid.bool(), sdg, "te", cfg, keep)
+    attn5 = attn.view(16, B, h, h, T).permute(0, 1, 4, 2, 3)
+    emb4 = emb.view(B, h, h, 256).permute(0, 3, 1, 2)
+    g_attn = torch.randn(attn5.shape, generator=g)
+    g_emb = torch.randn(emb4.shape, generator=g)
+    loss = (attn5 * g_attn).sum() + ((emb4 * g_emb).sum() if with_emb else 0)
+    loss.backward()
+
+    ctx = make_ctx({k: v for k, v in sd.items()}, training=True)
+    xd = x.detach().cuda()
+    kd = keep.cuda() if drop else None
+    e_out, a_out = E.ltae_attention(ctx, xd, dates.cuda(), valid.view(-1).cuda(), "te", 16, 4, 256, 1000.0,
+                                    0.1 if drop else 0.0, with_emb, 0, kd)
+    assert float((a_out.cpu() - attn5).abs().max()) < 2e-6
+    if with_emb:
+        assert rel(e_out, emb4) < 1e-5
+    ctx.tape.grads[a_out.data_ptr()] = g_attn.cuda().contiguous()
+    if with_emb:
+        ctx.tape.grads[e_out.data_ptr()] = g_emb.cuda().contiguous()
+    ctx.tape.backward()
+    assert rel(ctx.tape.grads[xd.data_ptr()], x.grad) < 1e-4
+    gmax = max(float(v.grad.norm()) for v in sdg.values())
+    for k, v in sdg.items():
+        ref = v.grad
+        got = ctx.g[k].cpu()
+        assert float((got - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-6 * gmax, k
+
+
+@pytest.mark.parametrize("B,T,C,H,h,pad", [(2, 5, 64, 32, 4, True), (1, 4, 64, 128, 16, False), (2, 3, 128, 16, 16, True)])
+def test_temporal_aggregate_fwd_bwd(B, T, C, H, h, pad):
+    E, L = _engine()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, T, C, H, H, generator=g, requires_grad=True)
+    attn = torch.softmax(torch.randn(16, B, T, h, h, generator=g), dim=2).requires_grad_(True)
+    valid = torch.ones(B, T, dtype=torch.int32)
+    if pad:
+        valid[0, -1] = 0
+    ref = O.temporal_aggregate(x, ~valid.bool(), attn)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({})
+    xd, ad = x.detach().cuda(), attn.detach().cuda()
+    out = E.temporal_aggregate(ctx, xd, ad, valid.view(-1).cuda(), 16)
+    assert rel(out, ref) < 2e-6
+    seed_backward(ctx, out, gout)
+    assert rel(ctx.tape.grads[xd.data_ptr()], x.grad) < 2e-6
+    assert rel(ctx.tape.grads[ad.data_ptr()], attn.grad) < 1e-5
+
+
+def test_pixel_group_norm_and_dropout():
+    E, L = _engine()
+    g = torch.Generator().manual_seed(19)
+    B, C, h = 2, 128, 8
+    x = torch.randn(B, C, h, h, generator=g, requires_grad=True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    keep = (torch.rand(B * h * h, C, generator=g) >= 0.2).float()
+    xp = x.permute(0, 2, 3, 1).reshape(B * h * h, C)
+    yp = F.group_norm(xp * keep / 0.8, 16, gamma, beta, 1e-5)
+    ref = yp.view(B, h, h, C).permute(0, 3, 1, 2)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({"on.weight": gamma.detach(), "on.bias": beta.detach()})
+    xd = x.detach().cuda()
+    o = E.dropout_nchw(ctx, xd, 0.2, 0, keep.cuda())
+    out = E.pixel_group_norm(ctx, o, "on", 16)
+    assert rel(out, ref) < 2e-6
+    seed_backward(ctx, out, gout)
+    assert rel(ctx.tape.grads[xd.data_ptr()], x.grad) < 2e-5
+    assert rel(ctx.g["on.weight"], gamma.grad) < 2e-5
+    assert rel(ctx.g["on.bias"], beta.grad) < 2e-5
+
+
+def test_cross_entropy_and_adam():
+    E, L = _engine()
+    g = torch.Generator().manual_seed(23)
+    logits = torch.randn(3, 15, 32, 32, generator=g, requires_grad=True)
+    y = torch.randint(0, 15, (3, 32, 32), generator=g)
+    ref = O.cross_entropy(logits, y, 15)
+    ref.backward()
+    cw = torch.ones(15)
+    cw[-1] = 0
+    loss, gl = E.cross_entropy(logits.detach().cuda(), y.cuda(), cw.cuda(), E.Workspace(torch.device("cuda")), True)
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel(gl, logits.grad) < 1e-5
+    # Adam: three steps against the oracle's restatement of torch.optim.Adam defaults
+    p = {"w": torch.randn(1000, generator=g)}
+    m, v = {"w": torch.zeros(1000)}, {"w": torch.zeros(1000)}
+    pd, md, vd = p["w"].clone().cuda(), torch.zeros(1000).cuda(), torch.zeros(1000).cuda()
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        O.adam_step(p, {"w": gr}, m, v, step)
+        E.adam_flat(pd, gr.cuda(), md, vd, step)
+    assert rel(pd, p["w"]) < 1e-6
+
+
+def test_frame_flags():
+    E, L = _engine()
+    x = torch.randn(2, 5, 10, 32, 32)
+    x[0, 3:] = 0
+    x[1, 4, :, 5, 5] = 0     # a few zeros inside a real frame do not make it padding
+    v = E.frame_flags(x.cuda(), 0.0).cpu().view(2, 5)
+    assert v.tolist() == [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]]
