@@ -21,7 +21,7 @@ NORM_GROUP, NORM_BATCH = 0, 1
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "N", "C0", "C1", "Hin", "Win", "Cout", "CoutP", "Hout", "Wout", "OutH", "OutW", "KH", "KW", "S",
-        "pad_y", "pad_x", "pad_mode", "osy", "osx", "ooy", "oox", "accumulate")]
+        "pad_y", "pad_x", "pad_mode", "osy", "osx", "ooy", "oox", "accumulate", "reflect_adjoint")]
 
 
 class WgradDesc(C.Structure):
@@ -58,7 +58,6 @@ SIGNATURES = {
     "c2s_device_cus": (I, []),
     "c2s_pack_weights": (I, [P, P, I, I, I, I, L, L, C.POINTER(I), P]),
     "c2s_conv_igemm": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P]),
-    "c2s_conv_reflect_dgrad_border": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "c2s_wgrad_workspace_floats": (SZ, [C.POINTER(WgradDesc)]),
     "c2s_conv_wgrad": (I, [C.POINTER(WgradDesc), P, P, P, P, SZ, P, P]),
     "c2s_wgrad_reduce": (I, [C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, P]),

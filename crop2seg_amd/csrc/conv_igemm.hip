@@ -27,6 +27,11 @@ struct ConvParams {
     int C0, C1, Hin, Win, Cout, CoutP, Hout, Wout, OutH, OutW;
     int pad_y, pad_x, pad_mode, osy, osx, ooy, oox, accumulate;
     int log2fc, tiles_x;
+    // reflect-adjoint rules (data gradient of a reflect-padded convolution): for each dimension up to two rules
+    // (output position, tap, extra input index): the B operand of (position, tap) additionally reads `extra`.
+    int adj;            // 0 = off
+    int ay_pos[2], ay_tap[2], ay_src[2];
+    int ax_pos[2], ax_tap[2], ax_src[2];
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -108,6 +113,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
     const int aoff = lk * COT + li;
 
+    // reflect adjoint: LDS row / column of the extra input of each (fragment, rule), or -1
+    int ady[2][2], adx[2][2];
+    bool wave_adj = false;
+    if (p.adj) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = 2 * wave + q;
+            const int oy = oy0 + f * FR + fy, ox = ox0 + fx;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                ady[q][r] = (oy == p.ay_pos[r]) ? (p.ay_src[r] - oy0 * S + p.pad_y) : -1;
+                adx[q][r] = (ox == p.ax_pos[r]) ? (p.ax_src[r] - ox0 * S + p.pad_x) : -1;
+                any = any || ady[q][r] >= 0 || adx[q][r] >= 0;
+            }
+        }
+        wave_adj = __any(any);
+    }
+
     f32x16 acc[MF][2];
 #pragma unroll
     for (int m = 0; m < MF; ++m)
@@ -155,18 +179,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         for (int t = 0; t < NT; ++t) {
             const int ky = t / K, kx = t % K;
             const int bt = ky * cols + kx;
+            if (!wave_adj) {
 #pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
-                float a[MF], b[2];
+                for (int cp = 0; cp < CK / 2; ++cp) {
+                    float a[MF], b[2];
 #pragma unroll
-                for (int m = 0; m < MF; ++m) a[m] = Wl[(t * CK + 2 * cp) * COT + aoff + m * 32];
+                    for (int m = 0; m < MF; ++m) a[m] = Wl[(t * CK + 2 * cp) * COT + aoff + m * 32];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) b[q] = Xl[boff[q] + 2 * cp * plane + bt];
+                    for (int q = 0; q < 2; ++q) b[q] = Xl[boff[q] + 2 * cp * plane + bt];
 #pragma unroll
-                for (int m = 0; m < MF; ++m)
+                    for (int m = 0; m < MF; ++m)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+                        for (int q = 0; q < 2; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+                }
+            } else {
+                // border lanes: B(position, tap) = sum over {normal, extra row} x {normal, extra col}
+                int o_r[2], o_c[2], o_rc[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int f = 2 * wave + q;
+                    int ey = -1, ex = -1;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (p.ay_tap[r] == ky && ady[q][r] >= 0) ey = ady[q][r];
+                        if (p.ax_tap[r] == kx && adx[q][r] >= 0) ex = adx[q][r];
+                    }
+                    const int nrow = (f * FR + fy) * S + ky, ncol = fx * S + kx;
+                    o_r[q] = ey >= 0 ? lk * plane + ey * cols + ncol : -1;
+                    o_c[q] = ex >= 0 ? lk * plane + nrow * cols + ex : -1;
+                    o_rc[q] = (ey >= 0 && ex >= 0) ? lk * plane + ey * cols + ex : -1;
+                }
+#pragma unroll
+                for (int cp = 0; cp < CK / 2; ++cp) {
+                    float a[MF], b[2];
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) a[m] = Wl[(t * CK + 2 * cp) * COT + aoff + m * 32];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float v = Xl[boff[q] + 2 * cp * plane + bt];
+                        if (o_r[q] >= 0) v += Xl[o_r[q] + 2 * cp * plane];
+                        if (o_c[q] >= 0) v += Xl[o_c[q] + 2 * cp * plane];
+                        if (o_rc[q] >= 0) v += Xl[o_rc[q] + 2 * cp * plane];
+                        b[q] = v;
+                    }
+#pragma unroll
+                    for (int m = 0; m < MF; ++m)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -210,68 +272,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
         const long tc = e / coutP;
         const int c = (int)(tc % cin), t = (int)(tc / cin);
         wpk[e] = o < cout ? src[o * so + c * sc + tt.off[t]] : 0.f;
-    }
-}
-
-// Border terms of the reflect-pad adjoint.  One thread per (n, c, border pixel).
-__global__ void reflect_border_kernel(const float* __restrict__ gout, const float* __restrict__ w,
-                                      float* __restrict__ gin, const int* __restrict__ valid, int N, int Cin,
-                                      int Cout, int Hin, int Win, int K, int S, int nborder) {
-    const long total = (long)N * Cin * nborder;
-    const int Ho = Hin / S, Wo = Win / S;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int bi = (int)(e % nborder);
-        const long nc = e / nborder;
-        const int c = (int)(nc % Cin), n = (int)(nc / Cin);
-        if (valid != nullptr && valid[n] == 0) continue;
-        // enumerate border pixels: rows 1 and H-2 (all x), then cols 1 and W-2 for the remaining rows
-        int jy, jx;
-        if (bi < 2 * Win) {
-            jy = bi < Win ? 1 : Hin - 2;
-            jx = bi % Win;
-        } else {
-            const int k = bi - 2 * Win;           // (Hin-2) rows x 2 cols
-            const int rr = k >> 1;                 // index among rows != 1, H-2
-            int row = rr;                          // rows 0,2,3,...,H-3,H-1
-            if (row >= 1) row += 1;
-            if (row >= Hin - 2) row += 1;
-            jy = row;
-            jx = (k & 1) ? Win - 2 : 1;
-        }
-        int qys[2], qxs[2];
-        int ny = 0, nx = 0;
-        qys[ny++] = jy;
-        if (jy == 1) qys[ny++] = -1;
-        if (jy == Hin - 2) { if (ny < 2) qys[ny++] = Hin; else { /* H==3: both */ } }
-        qxs[nx++] = jx;
-        if (jx == 1) qxs[nx++] = -1;
-        if (jx == Win - 2) { if (nx < 2) qxs[nx++] = Win; }
-        // H-2 == 1 (H == 3) not supported (host checks H,W >= 4)
-        float acc = 0.f;
-        const float* gn = gout + (size_t)n * Cout * Ho * Wo;
-        for (int iy = 0; iy < ny; ++iy)
-            for (int ix = 0; ix < nx; ++ix) {
-                if (iy == 0 && ix == 0) continue;  // interior term done by the main data-gradient kernel
-                const int qy = qys[iy], qx = qxs[ix];
-                for (int ky = 0; ky < K; ++ky) {
-                    const int ny2 = qy + 1 - ky;
-                    if (ny2 < 0 || (ny2 % S) != 0) continue;
-                    const int py = ny2 / S;
-                    if (py >= Ho) continue;
-                    for (int kx = 0; kx < K; ++kx) {
-                        const int nx2 = qx + 1 - kx;
-                        if (nx2 < 0 || (nx2 % S) != 0) continue;
-                        const int px = nx2 / S;
-                        if (px >= Wo) continue;
-                        const float* wp = w + ((size_t)c * K + ky) * K + kx;   // + o*Cin*K*K
-                        const float* gp = gn + (size_t)py * Wo + px;            // + o*Ho*Wo
-                        float s = 0.f;
-                        for (int o = 0; o < Cout; ++o) s += wp[(size_t)o * Cin * K * K] * gp[(size_t)o * Ho * Wo];
-                        acc += s;
-                    }
-                }
-            }
-        gin[((size_t)n * Cin + c) * Hin * Win + (size_t)jy * Win + jx] += acc;
     }
 }
 
@@ -328,6 +328,27 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
     p.Hout = d->Hout; p.Wout = d->Wout; p.OutH = d->OutH; p.OutW = d->OutW;
     p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.pad_mode = d->pad_mode;
     p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox; p.accumulate = d->accumulate;
+    p.adj = d->reflect_adjoint;
+    for (int r = 0; r < 2; ++r) { p.ay_pos[r] = p.ax_pos[r] = -1; p.ay_tap[r] = p.ax_tap[r] = -1; p.ay_src[r] = p.ax_src[r] = 0; }
+    if (d->reflect_adjoint) {
+        C2S_REQUIRE(d->pad_mode == C2S_PAD_ZEROS && d->S == 1 && (d->KH == 3 || d->KH == 2),
+                    "conv_igemm: reflect_adjoint applies to the zero-padded 3x3 / 2x2-parity data-gradient launches");
+        C2S_REQUIRE(d->Hin >= 2 && d->Win >= 2 && d->Hin != 3 && d->Win != 3, "conv_igemm: reflect_adjoint needs planes of 2 or >= 4");
+        if (d->KH == 3) {
+            // dgrad of conv3x3(reflect pad 1): g_x[1] += w[0] g_y[0] ; g_x[H-2] += w[2] g_y[H-1]  (flipped taps 2 / 0)
+            C2S_REQUIRE(d->pad_y == 1 && d->pad_x == 1 && d->Hin == d->Hout && d->Win == d->Wout, "conv_igemm: bad 3x3 adjoint geometry");
+            p.ay_pos[0] = 1; p.ay_tap[0] = 2; p.ay_src[0] = 0;
+            p.ay_pos[1] = d->Hout - 2; p.ay_tap[1] = 0; p.ay_src[1] = d->Hin - 1;
+            p.ax_pos[0] = 1; p.ax_tap[0] = 2; p.ax_src[0] = 0;
+            p.ax_pos[1] = d->Wout - 2; p.ax_tap[1] = 0; p.ax_src[1] = d->Win - 1;
+        } else {
+            // parity sub-kernel of the dgrad of conv4x4s2(reflect pad 1); parity = 1 - pad
+            if (d->pad_y == 0) { p.ay_pos[0] = 0; p.ay_tap[0] = 1; p.ay_src[0] = 0; }
+            else { p.ay_pos[0] = d->Hout - 1; p.ay_tap[0] = 0; p.ay_src[0] = d->Hin - 1; }
+            if (d->pad_x == 0) { p.ax_pos[0] = 0; p.ax_tap[0] = 1; p.ax_src[0] = 0; }
+            else { p.ax_pos[0] = d->Wout - 1; p.ax_tap[0] = 0; p.ax_src[0] = d->Win - 1; }
+        }
+    }
     int l2 = 5;
     while (l2 > 2 && (1 << l2) > d->Wout) --l2;
     p.log2fc = l2;
@@ -346,18 +367,4 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
 #undef C2S_DISPATCH
     c2s_set_error("conv_igemm: unsupported (K=%d,S=%d)", d->KH, d->S);
     return C2S_EINVAL;
-}
-
-extern "C" int c2s_conv_reflect_dgrad_border(const float* gout, const float* w, float* gin, const int* valid, int N,
-                                             int Cin, int Cout, int Hin, int Win, int K, int S, void* stream) {
-    C2S_REQUIRE(gout && w && gin, "reflect_border: null pointer");
-    C2S_REQUIRE((K == 3 && S == 1) || (K == 4 && S == 2), "reflect_border: unsupported (K,S)");
-    C2S_REQUIRE(Hin >= 2 && Win >= 2 && Hin != 3 && Win != 3 && Hin % S == 0 && Win % S == 0, "reflect_border: plane must be 2x2 or >= 4x4");
-    const int nborder = 2 * Win + 2 * (Hin - 2);
-    const long total = (long)N * Cin * nborder;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(reflect_border_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gout, w, gin, valid, N,
-                       Cin, Cout, Hin, Win, K, S, nborder);
-    C2S_CHECK_LAUNCH("reflect_border");
-    return C2S_OK;
 }

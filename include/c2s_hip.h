@@ -73,17 +73,14 @@ typedef struct c2s_conv_desc {
     int pad_mode;         /* C2S_PAD_* */
     int osy, osx, ooy, oox; /* output placement stride / offset */
     int accumulate;       /* 0: out = r ; 1: out += r */
+    int reflect_adjoint;  /* 1: this launch is the (zero-padded) data gradient of a reflect-padded 3x3 conv, or one
+                             2x2 parity sub-kernel of the data gradient of a reflect-padded 4x4-stride-2 conv: the
+                             adjoint of the reflection (halo gradient folded back onto rows/cols 1 and H-2/W-2;
+                             reflection_pad2d_backward of conv.py:72-79) is applied inside the kernel */
 } c2s_conv_desc;
 
 int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const float* src1, const float* wpk,
                    const float* bias, float* out, const int* valid, void* stream);
-
-/* Border terms of the data gradient of a reflect-padded convolution (adjoint of reflection: the halo
- * gradient folds back onto rows/cols 1 and H-2 / W-2).  Call after the zero-padded c2s_conv_igemm data
- * gradient; adds into gin.  w is the *forward* weight in torch layout [Cout,Cin,KH,KW].
- * Replaces the reflection_pad2d_backward of conv.py:72-79.  Supported (K,S): (3,1), (4,2). */
-int c2s_conv_reflect_dgrad_border(const float* gout, const float* w, float* gin, const int* valid,
-                                  int N, int Cin, int Cout, int Hin, int Win, int K, int S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient (convolution_backward-weight of the same call sites), split-K over output tiles:

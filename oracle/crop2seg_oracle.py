@@ -75,6 +75,31 @@ class BNState:
 # --------------------------------------------------------------------------
 # elementary layers
 # --------------------------------------------------------------------------
+# ReLU probe.  Gradients of a ReLU network are discontinuous where a pre-activation is exactly 0: two valid fp32
+# evaluations (different summation order) can put an element with |pre-activation| ~ 1e-7 on different sides of
+# the kink, which changes every upstream gradient by O(1/sqrt(#elements)) (measured: 3e-4..1.6e-3 on a 128x128
+# block from ONE flipped element).  Tests therefore pick inputs whose fp64 evaluation keeps every pre-activation
+# away from 0: set RELU_PROBE = [] and read the smallest |pre-activation| of each ReLU after a forward.
+RELU_PROBE: Optional[list] = None
+
+
+def relu(x: Tensor) -> Tensor:
+    if RELU_PROBE is not None and x.numel():
+        RELU_PROBE.append(float(x.detach().abs().min()))
+    return F.relu(x)
+
+
+def relu_margin(fn) -> float:
+    """Smallest |pre-activation| over all ReLUs evaluated by fn()."""
+    global RELU_PROBE
+    RELU_PROBE = []
+    try:
+        with torch.no_grad():
+            fn()
+        return min(RELU_PROBE) if RELU_PROBE else float("inf")
+    finally:
+        RELU_PROBE = None
+
 def _pad2d(x: Tensor, p: int, mode: str) -> Tensor:
     if p == 0:
         return x
@@ -128,7 +153,7 @@ def conv_layer(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, k: in
             x = batch_norm(x, sd, np_, training, cfg, bn)
         elif norm == "instance":
             x = F.instance_norm(x, eps=cfg.eps)
-        x = F.relu(x)
+        x = relu(x)
     return x
 
 
@@ -184,10 +209,10 @@ def up_conv_block(x: Tensor, skip: Tensor, sd: State, prefix: str, cfg: Backbone
     """UpConvBlock (conv.py:362-413): skip 1x1+BN+ReLU; ConvTranspose2d(k,s,p)+BN+ReLU;
     concat [up, skip]; conv1; out + conv2(out).  Norm is always 'batch' (utae.py:171)."""
     sk = F.conv2d(skip, sd[prefix + ".skip_conv.0.weight"], sd[prefix + ".skip_conv.0.bias"])
-    sk = F.relu(batch_norm(sk, sd, prefix + ".skip_conv.1", training, cfg, bn))
+    sk = relu(batch_norm(sk, sd, prefix + ".skip_conv.1", training, cfg, bn))
     up = F.conv_transpose2d(x, sd[prefix + ".up.0.weight"], sd[prefix + ".up.0.bias"],
                             stride=cfg.str_conv_s, padding=cfg.str_conv_p)
-    up = F.relu(batch_norm(up, sd, prefix + ".up.1", training, cfg, bn))
+    up = relu(batch_norm(up, sd, prefix + ".up.1", training, cfg, bn))
     o = torch.cat([up, sk], dim=1)
     o = conv_layer(o, sd, prefix + ".conv1", 1, "batch", 3, 1, 1, cfg, training, bn)
     return o + conv_layer(o, sd, prefix + ".conv2", 1, "batch", 3, 1, 1, cfg, training, bn)
@@ -249,7 +274,7 @@ def ltae(x: Tensor, dates: Tensor, pad_mask: Optional[Tensor], sd: State, prefix
     emb, attn = ltae_attention(x, dates, pad_mask, sd, prefix, cfg, attn_keep)
     o = F.linear(emb, sd[prefix + ".mlp.0.weight"], sd[prefix + ".mlp.0.bias"])     # tae.py:443
     o = batch_norm(o, sd, prefix + ".mlp.2", training, cfg, bn)                     # BN1d over P (tae.py:445)
-    o = F.relu(o)
+    o = relu(o)
     if mlp_keep is not None:
         o = o * mlp_keep / (1.0 - cfg.mlp_dropout)                                  # tae.py:448
     o = F.group_norm(o, cfg.n_head, sd[prefix + ".out_norm.weight"], sd[prefix + ".out_norm.bias"], cfg.eps)

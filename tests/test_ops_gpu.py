@@ -330,3 +330,57 @@ def test_frame_flags():
     x[1, 4, :, 5, 5] = 0     # a few zeros inside a real frame do not make it padding
     v = E.frame_flags(x.cuda(), 0.0).cpu().view(2, 5)
     assert v.tolist() == [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]]
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("hw", [8, 32, 64])   # inputs are chosen kink-free (oracle.relu_margin), see O.RELU_PROBE
+def test_up_conv_block_fwd_bwd(training, hw):
+    """UpConvBlock (reference conv.py:362-413) as one unit, BatchNorm in train and eval mode."""
+    from oracle import seeded
+    from crop2seg_amd.backbones import functional as Fn
+    E, L = _engine()
+    d_in, d_out, d_skip = 64, 32, 64
+    ks = [("u.skip_conv.0.weight", (d_skip, d_skip, 1, 1)), ("u.skip_conv.0.bias", (d_skip,)),
+          ("u.skip_conv.1.weight", (d_skip,)), ("u.skip_conv.1.bias", (d_skip,)),
+          ("u.skip_conv.1.running_mean", (d_skip,)), ("u.skip_conv.1.running_var", (d_skip,)),
+          ("u.skip_conv.1.num_batches_tracked", ()),
+          ("u.up.0.weight", (d_in, d_out, 4, 4)), ("u.up.0.bias", (d_out,)),
+          ("u.up.1.weight", (d_out,)), ("u.up.1.bias", (d_out,)),
+          ("u.up.1.running_mean", (d_out,)), ("u.up.1.running_var", (d_out,)), ("u.up.1.num_batches_tracked", ()),
+          ("u.conv1.conv.0.weight", (d_out, d_out + d_skip, 3, 3)), ("u.conv1.conv.0.bias", (d_out,)),
+          ("u.conv1.conv.1.weight", (d_out,)), ("u.conv1.conv.1.bias", (d_out,)),
+          ("u.conv1.conv.1.running_mean", (d_out,)), ("u.conv1.conv.1.running_var", (d_out,)),
+          ("u.conv1.conv.1.num_batches_tracked", ()),
+          ("u.conv2.conv.0.weight", (d_out, d_out, 3, 3)), ("u.conv2.conv.0.bias", (d_out,)),
+          ("u.conv2.conv.1.weight", (d_out,)), ("u.conv2.conv.1.bias", (d_out,)),
+          ("u.conv2.conv.1.running_mean", (d_out,)), ("u.conv2.conv.1.running_var", (d_out,)),
+          ("u.conv2.conv.1.num_batches_tracked", ())]
+    sd = seeded.make_state(ks, 31, "tame")
+    cfg = O.BackboneConfig()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for seed in range(33, 33 + 200):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(2, d_in, hw // 2, hw // 2, generator=g)
+        skip = torch.randn(2, d_skip, hw, hw, generator=g)
+        if O.relu_margin(lambda: O.up_conv_block(x.double(), skip.double(), sd64, "u", cfg, training, None)) > 2e-6:
+            break
+    x.requires_grad_(True)
+    skip.requires_grad_(True)
+    pnames = [k for k in sd if sd[k].is_floating_point() and "running" not in k]
+    sdg = {k: (v.clone().requires_grad_(True) if k in pnames else v.clone()) for k, v in sd.items()}
+    ref = O.up_conv_block(x, skip, sdg, "u", cfg, training, O.BNState())
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    params = {k: sd[k] for k in pnames}
+    bufs = {k: sd[k] for k in sd if k not in pnames}
+    ctx = make_ctx(params, bufs, training=training)
+    xd, sk = x.detach().cuda(), skip.detach().cuda()
+    out = Fn.up_conv_block(ctx, xd, sk, "u", Fn.BackboneSpec())
+    assert rel(out, ref) < 5e-6
+    seed_backward(ctx, out, gout)
+    assert rel(ctx.tape.grads[xd.data_ptr()], x.grad) < 5e-5
+    assert rel(ctx.tape.grads[sk.data_ptr()], skip.grad) < 5e-5
+    gmax = max(float(sdg[k].grad.norm()) for k in pnames)
+    for k in pnames:
+        ref_g = sdg[k].grad
+        assert float((ctx.g[k].cpu() - ref_g).norm()) <= 5e-5 * float(ref_g.norm()) + 1e-6 * gmax, k
