@@ -49,7 +49,7 @@ struct Cfg {
     static constexpr int MAXE = (CK * max_plane(K, S) + 255) / 256;
 };
 
-template <int K, int S, int MF>
+template <int K, int S, int MF, bool ADJ>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr int CK = Cfg<K, S>::CK;
     constexpr int NT = Cfg<K, S>::NT;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     // reflect adjoint: LDS row / column of the extra input of each (fragment, rule), or -1
     int ady[2][2], adx[2][2];
     bool wave_adj = false;
-    if (p.adj) {
+    if constexpr (ADJ) {
         bool any = false;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
         __syncthreads();
         // ---- MFMA
+        if (!ADJ || !wave_adj) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int ky = t / K, kx = t % K;
-            const int bt = ky * cols + kx;
-            if (!wave_adj) {
+            for (int t = 0; t < NT; ++t) {
+                const int ky = t / K, kx = t % K;
+                const int bt = ky * cols + kx;
 #pragma unroll
                 for (int cp = 0; cp < CK / 2; ++cp) {
                     float a[MF], b[2];
@@ -193,9 +193,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                         for (int q = 0; q < 2; ++q)
                             acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
                 }
-            } else {
-                // border lanes: B(position, tap) = sum over {normal, extra row} x {normal, extra col}
+            }
+        } else {
+            // waves that own border positions: B(position, tap) = sum over {normal, extra row} x {normal, extra col};
+            // branch-free (unused extras read the normal address with weight 0); tap loop kept rolled to bound registers
+#pragma unroll 1
+            for (int t = 0; t < NT; ++t) {
+                const int ky = t / K, kx = t % K;
+                const int bt = ky * cols + kx;
                 int o_r[2], o_c[2], o_rc[2];
+                float m_r[2], m_c[2], m_rc[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int f = 2 * wave + q;
@@ -206,9 +213,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                         if (p.ax_tap[r] == kx && adx[q][r] >= 0) ex = adx[q][r];
                     }
                     const int nrow = (f * FR + fy) * S + ky, ncol = fx * S + kx;
-                    o_r[q] = ey >= 0 ? lk * plane + ey * cols + ncol : -1;
-                    o_c[q] = ex >= 0 ? lk * plane + nrow * cols + ex : -1;
-                    o_rc[q] = (ey >= 0 && ex >= 0) ? lk * plane + ey * cols + ex : -1;
+                    const int base = lk * plane;
+                    o_r[q] = base + (ey >= 0 ? ey : nrow) * cols + ncol;
+                    o_c[q] = base + nrow * cols + (ex >= 0 ? ex : ncol);
+                    o_rc[q] = base + (ey >= 0 ? ey : nrow) * cols + (ex >= 0 ? ex : ncol);
+                    m_r[q] = ey >= 0 ? 1.f : 0.f;
+                    m_c[q] = ex >= 0 ? 1.f : 0.f;
+                    m_rc[q] = (ey >= 0 && ex >= 0) ? 1.f : 0.f;
                 }
 #pragma unroll
                 for (int cp = 0; cp < CK / 2; ++cp) {
@@ -218,9 +229,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         float v = Xl[boff[q] + 2 * cp * plane + bt];
-                        if (o_r[q] >= 0) v += Xl[o_r[q] + 2 * cp * plane];
-                        if (o_c[q] >= 0) v += Xl[o_c[q] + 2 * cp * plane];
-                        if (o_rc[q] >= 0) v += Xl[o_rc[q] + 2 * cp * plane];
+                        v = fmaf(m_r[q], Xl[o_r[q] + 2 * cp * plane], v);
+                        v = fmaf(m_c[q], Xl[o_c[q] + 2 * cp * plane], v);
+                        v = fmaf(m_rc[q], Xl[o_rc[q] + 2 * cp * plane], v);
                         b[q] = v;
                     }
 #pragma unroll
@@ -275,7 +286,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
     }
 }
 
-template <int K, int S, int MF>
+template <int K, int S, int MF, bool ADJ>
 int launch_conv(const ConvParams& p, int N, int tiles, hipStream_t st) {
     constexpr int CK = Cfg<K, S>::CK;
     constexpr int NT = Cfg<K, S>::NT;
@@ -284,12 +295,12 @@ int launch_conv(const ConvParams& p, int N, int tiles, hipStream_t st) {
     const size_t lds = ((size_t)CK * rows * cols + (size_t)NT * CK * 32 * MF) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<K, S, MF>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<K, S, MF, ADJ>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(tiles, p.CoutP / (32 * MF), N);
-    hipLaunchKernelGGL((conv_igemm_kernel<K, S, MF>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<K, S, MF, ADJ>), grid, dim3(256), lds, st, p);
     C2S_CHECK_LAUNCH("conv_igemm");
     return C2S_OK;
 }
@@ -357,13 +368,15 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
     const int tiles = p.tiles_x * cdiv(d->Hout, 8 * FR);
     hipStream_t st = (hipStream_t)stream;
     const bool wide = d->CoutP % 64 == 0;
-#define C2S_DISPATCH(K_, S_)                                            \
-    if (d->KH == K_ && d->S == S_)                                      \
-        return wide ? launch_conv<K_, S_, 2>(p, d->N, tiles, st) : launch_conv<K_, S_, 1>(p, d->N, tiles, st);
-    C2S_DISPATCH(3, 1)
-    C2S_DISPATCH(1, 1)
-    C2S_DISPATCH(2, 1)
-    C2S_DISPATCH(4, 2)
+#define C2S_DISPATCH(K_, S_, A_)                                        \
+    if (d->KH == K_ && d->S == S_ && (p.adj != 0) == A_)                \
+        return wide ? launch_conv<K_, S_, 2, A_>(p, d->N, tiles, st) : launch_conv<K_, S_, 1, A_>(p, d->N, tiles, st);
+    C2S_DISPATCH(3, 1, false)
+    C2S_DISPATCH(3, 1, true)
+    C2S_DISPATCH(1, 1, false)
+    C2S_DISPATCH(2, 1, false)
+    C2S_DISPATCH(2, 1, true)
+    C2S_DISPATCH(4, 2, false)
 #undef C2S_DISPATCH
     c2s_set_error("conv_igemm: unsupported (K=%d,S=%d)", d->KH, d->S);
     return C2S_EINVAL;

@@ -50,8 +50,11 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     float* ABl = Ul + NH * C;     // [C][16][2]
     float* Sl = ABl + C * 32;     // [T][16][16]
     const int tid = threadIdx.x, px = tid & 15, hh = tid >> 4;
-    const int tiles_per_b = HW / 16;
-    const int b = blockIdx.x / tiles_per_b, pix = (blockIdx.x % tiles_per_b) * 16 + px;
+    const int tiles_per_b = (HW + 15) / 16;
+    const int b = blockIdx.x / tiles_per_b;
+    const int pix_raw = (blockIdx.x % tiles_per_b) * 16 + px;
+    const bool act = pix_raw < HW;                       // partial last tile: idle lanes shadow the last pixel
+    const int pix = act ? pix_raw : HW - 1;
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
     for (int i = tid; i < NH * C; i += 256) Ul[i] = p.U[i];
@@ -71,8 +74,10 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
                 m2 += d * d;
             }
         const float rstd = rsqrtf(m2 * inv_n + p.eps);
-        p.stats[(pidx * NH + hh) * 2] = mean;
-        p.stats[(pidx * NH + hh) * 2 + 1] = rstd;
+        if (act) {
+            p.stats[(pidx * NH + hh) * 2] = mean;
+            p.stats[(pidx * NH + hh) * 2 + 1] = rstd;
+        }
         for (int cc = 0; cc < cpg; ++cc) {
             const int c = hh * cpg + cc;
             const float a = p.gamma[c] * rstd;
@@ -108,8 +113,10 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
         const float a = Sl[(t * 16 + hh) * 16 + px] * inv_den;
         const float ad = a * keep_scale(p, hh, Ptot, pidx, t);
         const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
-        if (p.attn_pre != nullptr) p.attn_pre[o] = a;
-        p.attn[o] = ad;
+        if (act) {
+            if (p.attn_pre != nullptr) p.attn_pre[o] = a;
+            p.attn[o] = ad;
+        }
         Sl[(t * 16 + hh) * 16 + px] = ad;
         asum += ad;
     }
@@ -134,8 +141,10 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
 #pragma unroll
         for (int j = 0; j < DV; ++j) o[j] += ad * p.pe[(b * T + t) * DV + j];
     }
+    if (act) {
 #pragma unroll
-    for (int j = 0; j < DV; ++j) p.emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] = o[j];
+        for (int j = 0; j < DV; ++j) p.emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] = o[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward, part 1
@@ -148,8 +157,12 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
     float* Dl = ABl + C * 32;     // [T][16][16]  dot -> ga -> gs
     float* Al = Dl + T * 256;     // [T][16][16]  attn (post-dropout)
     const int tid = threadIdx.x, px = tid & 15, hh = tid >> 4;
-    const int tiles_per_b = HW / 16;
-    const int b = blockIdx.x / tiles_per_b, pix = (blockIdx.x % tiles_per_b) * 16 + px;
+    const int tiles_per_b = (HW + 15) / 16;
+    const int b = blockIdx.x / tiles_per_b;
+    const int pix_raw = (blockIdx.x % tiles_per_b) * 16 + px;
+    const bool act = pix_raw < HW;
+    const float actf = act ? 1.f : 0.f;
+    const int pix = act ? pix_raw : HW - 1;
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
     const float* xb = p.x + (size_t)b * T * C * HW + pix;
@@ -202,15 +215,15 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
         const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
         const float gs = p.attn_pre_in[o] * (Dl[(t * 16 + hh) * 16 + px] - dsum);
         Dl[(t * 16 + hh) * 16 + px] = gs;
-        p.GS[o] = gs;
+        if (act) p.GS[o] = gs;
         // d s0[b,t,h]: sum over the 16 pixels of the tile
-        float r = gs;
+        float r = gs * actf;
         r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
         if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + hh] = r;
     }
 #pragma unroll
     for (int j = 0; j < DV; ++j) {
-        float r = ge[j] * asum;
+        float r = ge[j] * asum * actf;
         r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
         if (px == 0) p.part_bc[(size_t)blockIdx.x * NH * DV + hh * DV + j] = r;
     }
@@ -227,8 +240,10 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
         }
         const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
         const size_t o = (((size_t)b * NH + hh) * C + c) * HW + pix;
-        p.V[o] = a * v + bb * gssum;
-        p.Z[o] = a * z + bb * asum;
+        if (act) {
+            p.V[o] = a * v + bb * gssum;
+            p.Z[o] = a * z + bb * asum;
+        }
     }
 }
 
@@ -242,18 +257,22 @@ __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
     float* Gl = GEl + 256 * 16;     // [T][16][16] gs
     float* Al = Gl + T * 256;       // [T][16][16] attn
     const int tid = threadIdx.x, px = tid & 15, g = tid >> 4;
-    const int tiles_per_b = HW / 16;
-    const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * 16, pix = pix0 + px;
+    const int tiles_per_b = (HW + 15) / 16;
+    const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * 16;
+    const bool act = pix0 + px < HW;
+    const float actf = act ? 1.f : 0.f;
+    const int pix = act ? pix0 + px : HW - 1;
     const long pidx = (long)b * HW + pix;
     const int cpg = C / NH;
     for (int i = tid; i < NH * C; i += 256) Ul[i] = p.U[i];
     for (int i = tid; i < 256 * 16; i += 256) {
         const int ch = i >> 4, q = i & 15;
-        GEl[i] = p.g_emb != nullptr ? p.g_emb[((size_t)b * 256 + ch) * HW + pix0 + q] : 0.f;
+        const int pq = pix0 + q < HW ? pix0 + q : HW - 1;
+        GEl[i] = p.g_emb != nullptr ? p.g_emb[((size_t)b * 256 + ch) * HW + pq] : 0.f;
     }
     for (int i = tid; i < T * 256; i += 256) {
         const int q = i & 15, h = (i >> 4) & 15, t = i >> 8;
-        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix0 + q;
+        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + (pix0 + q < HW ? pix0 + q : HW - 1);
         Gl[i] = p.GS[o];
         Al[i] = p.attn_in[o];
     }
@@ -287,8 +306,10 @@ __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
             const float dxn = gxh * gm;
             m1 += dxn;
             m2 += dxn * xn;
-            gxb[(size_t)(t * C + c) * HW] = dxn;
+            if (act) gxb[(size_t)(t * C + c) * HW] = dxn;
         }
+        dg *= actf;
+        db *= actf;
         dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
         db += __shfl_xor(db, 1, 64); db += __shfl_xor(db, 2, 64); db += __shfl_xor(db, 4, 64); db += __shfl_xor(db, 8, 64);
         if (px == 0) {
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
         for (int t = 0; t < T; ++t) {
             const size_t o = (size_t)(t * C + c) * HW;
             const float xn = (xb[o] - mean) * rstd;
-            gxb[o] = rstd * (gxb[o] - m1 - xn * m2);
+            if (act) gxb[o] = rstd * (gxb[o] - m1 - xn * m2);
         }
     }
 }
@@ -451,7 +472,6 @@ int check(const c2s_ltae_desc* d) {
     C2S_REQUIRE(d && d->B > 0 && d->T > 0 && d->C > 0 && d->HW > 0, "ltae: bad shape");
     C2S_REQUIRE(d->n_head == NH && d->d_model == NH * DV, "ltae: only n_head=16, d_model=256 are built");
     C2S_REQUIRE(d->C % NH == 0 && d->C / NH <= 16, "ltae: C must be a multiple of 16 and <= 256");
-    C2S_REQUIRE(d->HW % 16 == 0, "ltae: h*w must be a multiple of 16");
     C2S_REQUIRE(bwd2_lds(d) <= 160 * 1024 && fwd_lds(d) <= 160 * 1024, "ltae: T*C too large for the LDS tile");
     C2S_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "ltae: bad dropout p");
     return C2S_OK;
@@ -481,7 +501,7 @@ extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const f
                             160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * (d->HW / 16)), dim3(256), fwd_lds(d), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * ((d->HW + 15) / 16)), dim3(256), fwd_lds(d), (hipStream_t)stream, p);
     C2S_CHECK_LAUNCH("ltae_fwd");
     return C2S_OK;
 }
@@ -490,7 +510,7 @@ extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const f
 //            | part_gb [tiles][C][2]
 extern "C" size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d) {
     if (!d) return 0;
-    const size_t tiles = (size_t)d->B * (d->HW / 16);
+    const size_t tiles = (size_t)d->B * ((d->HW + 15) / 16);
     return (size_t)NH * d->B * d->T * d->HW + 2 * (size_t)d->B * NH * d->C * d->HW + tiles * d->T * NH + tiles * 256 +
            tiles * d->C * 2;
 }
@@ -507,7 +527,7 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
                 "ltae_bwd: null pointer");
     C2S_REQUIRE(ws_floats >= c2s_ltae_bwd_workspace_floats(d), "ltae_bwd: workspace too small");
     (void)s0; (void)valid;
-    const size_t tiles = (size_t)d->B * (d->HW / 16);
+    const size_t tiles = (size_t)d->B * ((d->HW + 15) / 16);
     LtaeParams p = {};
     fill(p, d);
     p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.Wc = Wc; p.bc = bc; p.pe = pe;
@@ -532,7 +552,7 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     hipLaunchKernelGGL(ltae_bwd_gx_kernel, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
     C2S_CHECK_LAUNCH("ltae_bwd_gx");
     // reductions
-    const int tpb = d->HW / 16;
+    const int tpb = (d->HW + 15) / 16;
     {   // gs0[b][t][h] = sum over the tiles of b
         const long total = (long)d->B * d->T * NH;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.part_s0, gs0, tpb,

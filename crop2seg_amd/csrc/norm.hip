@@ -82,8 +82,9 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restri
         if (!batch && valid != nullptr && valid[grp / d.groups] == 0) {
             for (int r = lane; r < cpg; r += 64) {
                 const long row = (long)(grp / d.groups) * d.C + (grp % d.groups) * cpg + r;
-                row_ab[row * 2] = 0.f;
-                row_ab[row * 2 + 1] = 0.f;
+                row_ab[row * 3] = 0.f;
+                row_ab[row * 3 + 1] = 0.f;
+                row_ab[row * 3 + 2] = 0.f;
             }
             if (lane == 0) { gstats[grp * 2] = 0.f; gstats[grp * 2 + 1] = 0.f; }
             return;
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restri
     for (int r = lane; r < n_rows; r += 64) {
         const long row = batch ? (long)r * d.C + grp : (long)(grp / d.groups) * d.C + (grp % d.groups) * cpg + r;
         const int c = (int)(row % d.C);
-        const float a = gamma[c] * rstd_f;
-        row_ab[row * 2] = a;
-        row_ab[row * 2 + 1] = beta[c] - mean_f * a;
+        row_ab[row * 3] = gamma[c] * rstd_f;
+        row_ab[row * 3 + 1] = beta[c];
+        row_ab[row * 3 + 2] = mean_f;
     }
 }
 
@@ -147,11 +148,11 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         for (int i = lane; i < len; i += 64) y[base + i] = pad_value;
         return;
     }
-    const float a = row_ab[row * 2], b = row_ab[row * 2 + 1];
+    const float a = row_ab[row * 3], b = row_ab[row * 3 + 1], mu = row_ab[row * 3 + 2];
     if ((len & 3) == 0) {
         for (int i = lane * 4; i < len; i += 256) {
             f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
-            v.x = a * v.x + b; v.y = a * v.y + b; v.z = a * v.z + b; v.w = a * v.w + b;
+            v.x = (v.x - mu) * a + b; v.y = (v.y - mu) * a + b; v.z = (v.z - mu) * a + b; v.w = (v.w - mu) * a + b;
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (res != nullptr) {
                 const f32x4 r = *reinterpret_cast<const f32x4*>(res + base + i);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         }
     } else {
         for (int i = lane; i < len; i += 64) {
-            float v = a * x[base + i] + b;
+            float v = (x[base + i] - mu) * a + b;
             if (relu) v = fmaxf(v, 0.f);
             if (res != nullptr) v += res[base + i];
             y[base + i] = v;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void norm_bwd_sums_kernel(const float* __restr
     const size_t base = (size_t)row * d.HW + beg;
     const int grp = d.kind == C2S_NORM_BATCH ? c : n * d.groups + c / (d.C / d.groups);
     const float mean = gstats[grp * 2], rstd = gstats[grp * 2 + 1];
-    const float a = row_ab[row * 2], b = row_ab[row * 2 + 1];
+    const float a = row_ab[row * 3], b = row_ab[row * 3 + 1];
     float s1 = 0.f, s2 = 0.f, sx = 0.f;
     if ((len & 3) == 0) {
         for (int i = lane * 4; i < len; i += 256) {
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void norm_bwd_sums_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xx = xv[k];
-                const float gg = (!relu || a * xx + b > 0.f) ? gv[k] : 0.f;
+                const float gg = (!relu || (xx - mean) * a + b > 0.f) ? gv[k] : 0.f;
                 s1 += gg;
                 s2 += gg * ((xx - mean) * rstd);
                 sx += xx;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void norm_bwd_sums_kernel(const float* __restr
     } else {
         for (int i = lane; i < len; i += 64) {
             const float xx = x[base + i];
-            const float gg = (!relu || a * xx + b > 0.f) ? g[base + i] : 0.f;
+            const float gg = (!relu || (xx - mean) * a + b > 0.f) ? g[base + i] : 0.f;
             s1 += gg;
             s2 += gg * ((xx - mean) * rstd);
             sx += xx;
@@ -233,7 +234,7 @@ __global__ void norm_bwd_rowsum_kernel(const float* __restrict__ part, float* __
     rowsum[row * 3] = (float)a; rowsum[row * 3 + 1] = (float)b; rowsum[row * 3 + 2] = (float)c;
 }
 
-// one wave per group: coefficients k1,k2,k3 per row ( dx = k1*g' + k2*x + k3 )
+// one wave per group: coefficients k1,k2,k3 per row ( dx = k1*g' + k2*(x-mean) + k3 )
 __global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restrict__ rowsum, const float* __restrict__ gamma,
                                                            const float* __restrict__ gstats, float* __restrict__ rowk,
                                                            const int* __restrict__ valid, c2s_norm_desc d) {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restri
     const bool batch = d.kind == C2S_NORM_BATCH;
     const int cpg = batch ? 1 : d.C / d.groups;
     const int n_rows = batch ? d.N : cpg;
-    const float mean = gstats[grp * 2], rstd = gstats[grp * 2 + 1];
+    const float rstd = gstats[grp * 2 + 1];
     double A = 0.0, Bv = 0.0, cnt = 0.0;
     for (int r = lane; r < n_rows; r += 64) {
         const long row = batch ? (long)r * d.C + grp : (long)(grp / d.groups) * d.C + (grp % d.groups) * cpg + r;
@@ -264,36 +265,48 @@ __global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restri
             k1 = rstd * gamma[row % d.C];
             if (!frozen) {
                 k2 = (float)(-(double)rstd * rstd * Bv / m);
-                k3 = (float)(-(double)rstd * A / m + (double)rstd * rstd * mean * Bv / m);
+                k3 = (float)(-(double)rstd * A / m);
             }
         }
         rowk[row * 3] = k1; rowk[row * 3 + 1] = k2; rowk[row * 3 + 2] = k3;
     }
 }
 
-// per channel: dgamma, dbeta, dbias (sum over frames)
-__global__ void norm_bwd_param_kernel(const float* __restrict__ rowsum, const float* __restrict__ rowk,
-                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
-                                      const int* __restrict__ valid, int N, int C, int HW) {
+// per channel: dgamma, dbeta (sum over frames)
+__global__ void norm_bwd_param_kernel(const float* __restrict__ rowsum, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, const int* __restrict__ valid, int N, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double dg = 0, db = 0, dbi = 0;
+    double dg = 0, db = 0;
     for (int n = 0; n < N; ++n) {
         if (valid != nullptr && valid[n] == 0) continue;
         const long row = (long)n * C + c;
-        const double s1 = rowsum[row * 3], s2 = rowsum[row * 3 + 1], sx = rowsum[row * 3 + 2];
-        dg += s2;
-        db += s1;
-        dbi += (double)rowk[row * 3] * s1 + (double)rowk[row * 3 + 1] * sx + (double)rowk[row * 3 + 2] * HW;
+        dg += rowsum[row * 3 + 1];
+        db += rowsum[row * 3];
     }
     if (dgamma != nullptr) dgamma[c] = (float)dg;
     if (dbeta != nullptr) dbeta[c] = (float)db;
-    if (dbias != nullptr) dbias[c] = (float)dbi;
+}
+
+// gradient of the producing convolution's bias: per-channel sum of dx, from the per-(row,segment) partials the
+// apply pass leaves in part[item*3]
+__global__ void norm_bwd_dbias_kernel(const float* __restrict__ part, float* __restrict__ dbias,
+                                      const int* __restrict__ valid, int N, int C, int segs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int n = 0; n < N; ++n) {
+        if (valid != nullptr && valid[n] == 0) continue;
+        const long row = (long)n * C + c;
+        for (int k = 0; k < segs; ++k) s += part[(row * segs + k) * 3];
+    }
+    dbias[c] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                              const float* __restrict__ row_ab,
                                                              const float* __restrict__ rowk, float* __restrict__ gx,
+                                                             float* __restrict__ part,
                                                              const int* __restrict__ valid, int C, int HW, int segs,
                                                              long nitems, int relu) {
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -307,10 +320,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     const size_t base = (size_t)row * HW + beg;
     if (valid != nullptr && valid[row / C] == 0) {
         for (int i = lane; i < len; i += 64) gx[base + i] = 0.f;
+        if (lane == 0) part[item * 3] = 0.f;
         return;
     }
-    const float a = row_ab[row * 2], b = row_ab[row * 2 + 1];
+    const float a = row_ab[row * 3], b = row_ab[row * 3 + 1], mu = row_ab[row * 3 + 2];
     const float k1 = rowk[row * 3], k2 = rowk[row * 3 + 1], k3 = rowk[row * 3 + 2];
+    float sdx = 0.f;
     if ((len & 3) == 0) {
         for (int i = lane * 4; i < len; i += 256) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
@@ -318,18 +333,24 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gg = (!relu || a * xv[k] + b > 0.f) ? gv[k] : 0.f;
-                o[k] = k1 * gg + k2 * xv[k] + k3;
+                const float xc = xv[k] - mu;
+                const float gg = (!relu || xc * a + b > 0.f) ? gv[k] : 0.f;
+                o[k] = k1 * gg + k2 * xc + k3;
+                sdx += o[k];
             }
             *reinterpret_cast<f32x4*>(gx + base + i) = o;
         }
     } else {
         for (int i = lane; i < len; i += 64) {
-            const float xx = x[base + i];
-            const float gg = (!relu || a * xx + b > 0.f) ? g[base + i] : 0.f;
-            gx[base + i] = k1 * gg + k2 * xx + k3;
+            const float xc = x[base + i] - mu;
+            const float gg = (!relu || xc * a + b > 0.f) ? g[base + i] : 0.f;
+            const float o = k1 * gg + k2 * xc + k3;
+            gx[base + i] = o;
+            sdx += o;
         }
     }
+    sdx = wave_sum(sdx);
+    if (lane == 0) part[item * 3] = sdx;
 }
 
 int check_desc(const c2s_norm_desc* d) {
@@ -407,11 +428,16 @@ extern "C" int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float*
     const int ngroups = d->kind == C2S_NORM_BATCH ? d->C : d->N * d->groups;
     hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3(ngroups), dim3(64), 0, st, rowsum, gamma, group_stats, rowk, valid, *d);
     C2S_CHECK_LAUNCH("norm_bwd_coef");
-    hipLaunchKernelGGL(norm_bwd_param_kernel, dim3(cdiv(d->C, 64)), dim3(64), 0, st, rowsum, rowk, dgamma, dbeta, dbias,
-                       valid, d->N, d->C, d->HW);
+    hipLaunchKernelGGL(norm_bwd_param_kernel, dim3(cdiv(d->C, 64)), dim3(64), 0, st, rowsum, dgamma, dbeta, valid, d->N,
+                       d->C);
     C2S_CHECK_LAUNCH("norm_bwd_param");
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(cdiv(nitems, 4)), dim3(256), 0, st, x, g, row_ab, rowk, gx, valid,
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(cdiv(nitems, 4)), dim3(256), 0, st, x, g, row_ab, rowk, gx, part, valid,
                        d->C, d->HW, segs, nitems, relu);
     C2S_CHECK_LAUNCH("norm_bwd_apply");
+    if (dbias != nullptr) {
+        hipLaunchKernelGGL(norm_bwd_dbias_kernel, dim3(cdiv(d->C, 64)), dim3(64), 0, st, part, dbias, valid, d->N, d->C,
+                           segs);
+        C2S_CHECK_LAUNCH("norm_bwd_dbias");
+    }
     return C2S_OK;
 }

@@ -343,7 +343,7 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
     rv = ctx.b.get(prefix + ".running_var") if batch else None
     ngroups = Cc if batch else N * groups
     gstats = torch.empty(ngroups * 2, device=x.device, dtype=torch.float32)
-    row_ab = torch.empty(N * Cc * 2, device=x.device, dtype=torch.float32)
+    row_ab = torch.empty(N * Cc * 3, device=x.device, dtype=torch.float32)   # per row: (scale, beta, mean)
     nws = lib().c2s_norm_workspace_floats(C.byref(d))
     ws = ctx.ws.get("norm", nws)
     check(lib().c2s_norm_stats(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),

@@ -118,11 +118,11 @@ int c2s_dwconv_wgrad(const float* in, const float* gout, float* partial, float* 
  * Normalisation + ReLU (+ residual), GroupNorm and train/eval BatchNorm share one set of kernels:
  *   rows = (frame n, channel c), each row = HW contiguous floats.
  *   c2s_norm_stats   : per-(row,segment) mean / M2 (two-pass, wave per segment) -> finalised per group
- *                      into per-row scale/shift  a[n,c], b[n,c]  (y = a*x + b), plus mean/rstd per group.
+ *                      into per-row (a, beta, mean)  row_ab[n,c,3]  (y = (x - mean)*a + beta), plus mean/rstd per group.
  *   c2s_norm_apply   : y = relu(a*x+b) (+ residual); rows of padded frames are filled with pad_value.
  *   c2s_norm_bwd     : given g = dL/dy: (1) per-row sums of g' = g*[y>0] and g'*xhat, (2) finalise:
  *                      dgamma, dbeta, dbias (gradient of the bias of the producing convolution) and the
- *                      per-row coefficients of  dx = k1*g' + k2*x + k3 , (3) elementwise dx.
+ *                      per-row coefficients of  dx = k1*g' + k2*(x-mean) + k3 , (3) elementwise dx.
  * Replaces nn.GroupNorm(4) + ReLU (conv.py:56-60,85-88), nn.BatchNorm2d + ReLU (conv.py:52-53,380,388),
  * the residual add of conv.py:292,410 and their backward ops.
  * stats layout: group stats [G2][2] = (mean, rstd), G2 = N*groups (GROUP) or C (BATCH).
@@ -164,7 +164,7 @@ int c2s_frame_flags(const float* x, int* valid, int N, long frame_elems, float p
  * (NULL for W-TAE's attention-only variant, tae.py:619); stats [P,16,2] = (mean, rstd); pe [B,T,16].
  * ------------------------------------------------------------------------------------------------ */
 typedef struct c2s_ltae_desc {
-    int B, T, C, HW;      /* HW = h*w pixels per frame at the L-TAE resolution (multiple of 16) */
+    int B, T, C, HW;      /* HW = h*w pixels per frame at the L-TAE resolution */
     int n_head, d_model;  /* built for 16 / 256 */
     float eps;
     float dropout_p;      /* 0 => no dropout */

@@ -56,20 +56,64 @@ class Golden:
     def grad_names(self):
         return sorted({k.split("/")[1] for k in self.z.files if k.startswith("grad/")})
 
-    def check_grad(self, name, g, rtol, atol_frac=1e-6):
-        """Compare a gradient tensor with the stored summary. Returns (rel_err, ref_norm)."""
+    def sample(self, name, g):
+        """Entries of gradient tensor g at the positions this fixture stores for `name` (float64, CPU)."""
         flat = g.detach().double().flatten().cpu()
-        ref_norm = float(self.z[f"grad/{name}/norm"])
         if f"grad/{name}/whole" in self.z:
-            ref = torch.from_numpy(self.z[f"grad/{name}/whole"]).double()
-            got = flat
-        else:
-            idx = torch.from_numpy(self.z[f"grad/{name}/idx"])
-            ref = torch.from_numpy(self.z[f"grad/{name}/val"]).double()
-            got = flat[idx]
-        err = float((got - ref).norm())
-        scale = float(ref.norm())
-        return err, scale, ref_norm, float(flat.norm())
+            return flat
+        return flat[torch.from_numpy(self.z[f"grad/{name}/idx"])]
+
+    def ref_sample(self, name):
+        key = f"grad/{name}/whole" if f"grad/{name}/whole" in self.z else f"grad/{name}/val"
+        return torch.from_numpy(self.z[key]).double()
+
+    def check_grad(self, name, g, rtol=0, atol_frac=1e-6):
+        """Compare a gradient tensor with the stored summary. Returns (err, scale, ref_norm, got_norm)."""
+        ref = self.ref_sample(name)
+        got = self.sample(name, g)
+        return (float((got - ref).norm()), float(ref.norm()), float(self.z[f"grad/{name}/norm"]),
+                float(g.detach().double().norm()))
+
+    def fp64_anchor(self):
+        """Train-mode gradient protocol.  BatchNorm-with-batch-statistics backward amplifies fp32
+        rounding: the reference's own fp32 gradients are 1e-3..3e-2 from an fp64 evaluation, so a per-tensor 1e-3 bar
+        against them is not meaningful.  Instead both the reference (stored golden) and the implementation under
+        test are measured against the fp64 CPU oracle on the stored entries:
+            err(impl, fp64) <= max(3 * err(reference_fp32, fp64), 1e-3 * scale).
+        Returns {name: (g64_sample, err_ref)} and keeps the oracle's own fp32 gradients in self.g32."""
+        if getattr(self, "_anchor", None) is None:
+            from oracle import crop2seg_oracle as O
+            kw = self.dropout_kwargs()
+            if self.cfg.model == "wtae":
+                kw.pop("mlp_keep", None)
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in self.sd.items()}
+            kw64 = {k: v.double() for k, v in kw.items()}
+            _, _, g64, _ = O.loss_and_grads(sd64, self.x.double(), self.dates, self.y, self.cfg, self.training, **kw64)
+            _, _, self.g32, _ = O.loss_and_grads(self.sd, self.x, self.dates, self.y, self.cfg, self.training, **kw)
+            self._anchor = {}
+            for n in g64:
+                s64 = self.sample(n, g64[n])
+                self._anchor[n] = (s64, float((self.ref_sample(n) - s64).norm()))
+        return self._anchor
+
+    def check_train_grad(self, name, g, gmax, abs_only):
+        """Assert the 8c.4 criterion for one tensor; returns err(impl, fp64) / scale."""
+        s64, err_ref = self.fp64_anchor()[name]
+        scale = float(s64.norm())
+        err = float((self.sample(name, g) - s64).norm())
+        if abs_only or scale < 1e-6 * gmax:
+            assert err <= 1e-4 * gmax, (name, err, gmax)
+            return 0.0
+        # sanity: the fp64 oracle and the reference's fp32 gradients agree to the reference's own fp32 noise
+        # (1e-3..6e-2 under weight_init-style BatchNorm gains, measured; a wrong oracle would be off by O(1))
+        sanity = 0.15 if self.meta["flavour"] == "wi" else 2e-2
+        assert err_ref <= sanity * scale + 1e-6 * gmax, ("fp64 oracle inconsistent with the reference", name, err_ref / scale)
+        # weight_init-style weights: near-zero BatchNorm gains put whole channels on the ReLU kink (no kink-free input
+        # exists, oracle/make_golden.py), and the reference's own fp32 gradients differ from themselves by 1.5-3.6e-2
+        # between thread counts there (SURVEY.md 8c) -> relative floor 1e-2 instead of 1e-3
+        floor = 1e-2 if self.meta["flavour"] == "wi" else 1e-3
+        assert err <= max(3 * err_ref, floor * scale) + 1e-6 * gmax, (name, err / scale, err_ref / scale)
+        return err / scale
 
 
 @pytest.fixture(scope="session")
