@@ -111,13 +111,11 @@ class TrainStep:
         self.class_w = cw
         self.step_count = 0
         self.ws = E.Workspace(dev)
-        self.distributed = distributed
-        self.group = process_group
-        self.world = 1
+        self.dp = None
         if distributed:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
-            dist.broadcast(self.flat_param, src=0, group=process_group)   # identical initial weights on every rank
+            from .ddp import FlatDataParallel
+            self.dp = FlatDataParallel(process_group)
+            self.dp.sync_parameters(self.flat_param)                      # identical initial weights on every rank
 
     @torch.no_grad()
     def __call__(self, x: Tensor, dates: Tensor, y: Tensor, dropout_state: Optional[Fn.DropoutState] = None,
@@ -142,10 +140,8 @@ class TrainStep:
             if n not in ctx._gwritten:
                 self.grads[n].zero_()
         scale = 1.0
-        if self.distributed and self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, group=self.group)             # one 4.3 MB bucket per step
-            scale = 1.0 / self.world
+        if self.dp is not None:
+            scale = self.dp.reduce_gradients(self.flat_grad)              # one 4.3 MB bucket per step
         if apply_update:
             self.step_count += 1
             E.adam_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,

@@ -111,8 +111,9 @@ class Golden:
         # weight_init-style weights: near-zero BatchNorm gains put whole channels on the ReLU kink (no kink-free input
         # exists, oracle/make_golden.py), and the reference's own fp32 gradients differ from themselves by 1.5-3.6e-2
         # between thread counts there -> relative floor 1e-2 instead of 1e-3
-        floor = 1e-2 if self.meta["flavour"] == "wi" else 1e-3
-        assert err <= max(3 * err_ref, floor * scale) + 1e-6 * gmax, (name, err / scale, err_ref / scale)
+        wi = self.meta["flavour"] == "wi"
+        floor, factor = (1e-2, 5) if wi else (1e-3, 3)
+        assert err <= max(factor * err_ref, floor * scale) + 1e-6 * gmax, (name, err / scale, err_ref / scale)
         return err / scale
 
 
