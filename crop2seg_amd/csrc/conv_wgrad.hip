@@ -161,6 +161,197 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fast path (planes whose width is a multiple of 32: every full-resolution / half-resolution layer).
+// Same decomposition as conv_wgrad_kernel, but the tile is 32 positions wide so every row segment of the input
+// tile (32*S floats + 1 halo column each side) and of the gout tile (32 floats) is 128-byte aligned: global
+// traffic is float4, and the loads of tile i+1 are issued into registers BEFORE the MFMA loop of tile i
+// (register-staged software pipeline, cdna_hip_programming.md T14): HBM/L2 latency hides under ~20k cycles of MFMA.
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
+    constexpr int TP = (S == 2) ? 64 : 128;
+    constexpr int PR = TP / 32;                    // tile rows
+    constexpr int NT = K * K, TH = (NT + 1) / 2;
+    constexpr int PAD = (K == 1) ? 0 : 1;
+    constexpr int XR = (PR - 1) * S + K;           // input tile rows
+    constexpr int XC = 31 * S + K;                 // input tile cols
+    constexpr int HALO_R = XC - 32 * S - PAD;      // right halo columns (== 1 for K=3,S=1 and K=4,S=2; 0 for K=1)
+    constexpr int PLANE = XR * XC, PLANEP = PLANE | 1;
+    constexpr int V4 = 8 * S;                      // float4 per interior row
+    constexpr int NXI = 32 * XR * V4;              // interior float4 items
+    constexpr int NXH = (PAD + HALO_R) * 32 * XR;  // halo scalars
+    constexpr int NG = 64 * PR * 8;                // gout float4 items
+    constexpr int XI_PT = (NXI + 255) / 256, XH_PT = (NXH + 255) / 256, G_PT = NG / 256;
+    static_assert(HALO_R == PAD, "halo is symmetric for the supported kernels");
+    extern __shared__ float lds[];
+    float* Xl = lds;                    // [32][PLANEP]
+    float* Gl = lds + 32 * PLANEP;      // [64][TP+1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int ofrag = wave & 1, thalf = wave >> 1;
+    const int cb = blockIdx.y * 32, ob = blockIdx.z * 64;
+    const int slice = blockIdx.x;
+    const int Cin = p.C0 + p.C1;
+    const int HWin = p.Hin * p.Win, HWo = p.Hout * p.Wout;
+    const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
+
+    f32x16 acc[TH];
+#pragma unroll
+    for (int i = 0; i < TH; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    f32x4 xi[XI_PT];
+    float xh[XH_PT > 0 ? XH_PT : 1];
+    f32x4 gv[G_PT];
+
+    // issue the global loads of one tile into registers
+    auto prefetch = [&](int tile) {
+        const int n = tile / (p.tiles_x * p.tiles_y);
+        const int trem = tile - n * (p.tiles_x * p.tiles_y);
+        const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+        const int oy0 = tyi * PR, ox0 = txi * 32;
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HWin;
+        const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HWin : nullptr;
+#pragma unroll
+        for (int i = 0; i < XI_PT; ++i) {
+            const int e = tid + i * 256;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < NXI) {
+                const int j = e % V4, rr = e / V4;
+                const int r = rr % XR, c = rr / XR;
+                int gy = oy0 * S - PAD + r;
+                bool ok = true;
+                if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
+                const int cg = cb + c;
+                if (ok && cg < Cin) {
+                    const float* sp = cg < p.C0 ? s0n + (size_t)cg * HWin : s1n + (size_t)(cg - p.C0) * HWin;
+                    v = *reinterpret_cast<const f32x4*>(sp + (size_t)gy * p.Win + ox0 * S + 4 * j);
+                }
+            }
+            xi[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XH_PT; ++i) {
+            const int e = tid + i * 256;
+            float v = 0.f;
+            if (e < NXH) {
+                const int side = e & 1, rr = e >> 1;          // PAD + HALO_R == 2
+                const int r = rr % XR, c = rr / XR;
+                int gy = oy0 * S - PAD + r;
+                int gx = side == 0 ? ox0 * S - 1 : ox0 * S + 32 * S;
+                bool ok = true;
+                if (reflect) { gy = reflect_idx(gy, p.Hin); gx = reflect_idx(gx, p.Win); }
+                else ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const int cg = cb + c;
+                if (ok && cg < Cin) {
+                    const float* sp = cg < p.C0 ? s0n + (size_t)cg * HWin : s1n + (size_t)(cg - p.C0) * HWin;
+                    v = sp[(size_t)gy * p.Win + gx];
+                }
+            }
+            xh[i] = v;
+        }
+        const float* gn = p.gout + (size_t)n * p.Cout * HWo;
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int e = tid + i * 256;
+            const int j = e & 7, rr = e >> 3;
+            const int r = rr % PR, o = rr / PR;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ob + o < p.Cout)
+                v = *reinterpret_cast<const f32x4*>(gn + (size_t)(ob + o) * HWo + (size_t)(oy0 + r) * p.Wout + ox0 + 4 * j);
+            gv[i] = v;
+        }
+    };
+    // registers -> LDS (odd plane strides: channel-varying lanes of the MFMA reads hit distinct banks)
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < XI_PT; ++i) {
+            const int e = tid + i * 256;
+            if (e < NXI) {
+                const int j = e % V4, rr = e / V4;
+                const int r = rr % XR, c = rr / XR;
+                float* d = Xl + c * PLANEP + r * XC + PAD + 4 * j;
+                d[0] = xi[i].x; d[1] = xi[i].y; d[2] = xi[i].z; d[3] = xi[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XH_PT; ++i) {
+            const int e = tid + i * 256;
+            if (e < NXH) {
+                const int side = e & 1, rr = e >> 1;
+                const int r = rr % XR, c = rr / XR;
+                Xl[c * PLANEP + r * XC + (side == 0 ? 0 : XC - 1)] = xh[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int e = tid + i * 256;
+            const int j = e & 7, rr = e >> 3;
+            const int r = rr % PR, o = rr / PR;
+            float* d = Gl + o * (TP + 1) + r * 32 + 4 * j;
+            d[0] = gv[i].x; d[1] = gv[i].y; d[2] = gv[i].z; d[3] = gv[i].w;
+        }
+    };
+
+    // tap offsets of this wave half
+    int toff[TH];
+#pragma unroll
+    for (int i = 0; i < TH; ++i) {
+        const int t = 2 * i + thalf;
+        toff[i] = (t / K) * XC + (t % K);
+    }
+
+    // next valid tile of this slice (padded frames are skipped)
+    auto next_tile = [&](int tile) {
+        while (tile < p.ntiles) {
+            const int n = tile / (p.tiles_x * p.tiles_y);
+            if (p.valid == nullptr || p.valid[n] != 0) break;
+            tile += p.nslices;
+        }
+        return tile;
+    };
+
+    int tile = next_tile(slice);
+    if (tile < p.ntiles) prefetch(tile);
+    while (tile < p.ntiles) {
+        commit();
+        __syncthreads();
+        const int nxt = next_tile(tile + p.nslices);
+        if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
+#pragma unroll 4
+        for (int kk = 0; kk < TP / 2; ++kk) {
+            const int q = 2 * kk + lk;
+            const int qy = q >> 5, qx = q & 31;
+            const float b = Gl[(ofrag * 32 + li) * (TP + 1) + q];
+            const int abase = li * PLANEP + (qy * S) * XC + qx * S;
+#pragma unroll
+            for (int i = 0; i < TH; ++i) {
+                if (2 * i + thalf < NT) {
+                    const float a = Xl[abase + toff[i]];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        tile = nxt;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TH; ++i) {
+        const int t = 2 * i + thalf;
+        if (t < NT) {
+            float* sl = p.slabs + (((size_t)slice * NT + t) * p.CinP + cb) * p.CoutB + ob + ofrag * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                sl[(size_t)ci * p.CoutB] = acc[i][r];
+            }
+        }
+    }
+}
+
 struct TapTable {
     int off[16];
 };
@@ -191,8 +382,36 @@ void geometry(const c2s_wgrad_desc* d, int TP, int* log2pc, int* tiles_x, int* t
 }
 
 template <int K, int S>
+int launch_wgrad_fast(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
+    constexpr int TP = (S == 2) ? 64 : 128, PR = TP / 32;
+    constexpr int XR = (PR - 1) * S + K, XC = 31 * S + K;
+    p.log2pc = 5;
+    p.tiles_x = d->Wout / 32;
+    p.tiles_y = d->Hout / PR;
+    p.ntiles = d->N * p.tiles_x * p.tiles_y;
+    const size_t lds = ((size_t)32 * ((XR * XC) | 1) + (size_t)64 * (TP + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_fast_kernel<K, S>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
+    hipLaunchKernelGGL((conv_wgrad_fast_kernel<K, S>), grid, dim3(256), lds, st, p);
+    C2S_CHECK_LAUNCH("conv_wgrad_fast");
+    return C2S_OK;
+}
+
+template <int K, int S>
 int launch_wgrad(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
     using C = WCfg<K, S>;
+    {   // fast path: 32-wide aligned tiles
+        constexpr int PR = C::TP / 32;
+        const int pad = (K == 1) ? 0 : 1;
+        if (d->Wout % 32 == 0 && d->Win == d->Wout * S && d->Hin == d->Hout * S && d->Hout % PR == 0 &&
+            d->pad_y == pad && d->pad_x == pad && d->Win % 4 == 0)
+            return launch_wgrad_fast<K, S>(d, p, st);
+    }
     geometry(d, C::TP, &p.log2pc, &p.tiles_x, &p.tiles_y);
     p.ntiles = d->N * p.tiles_x * p.tiles_y;
     const int PC = 1 << p.log2pc, PR = C::TP >> p.log2pc;
