@@ -27,11 +27,10 @@ struct ConvParams {
     int C0, C1, Hin, Win, Cout, CoutP, Hout, Wout, OutH, OutW;
     int pad_y, pad_x, pad_mode, osy, osx, ooy, oox, accumulate;
     int log2fc, tiles_x;
-    // reflect-adjoint rules (data gradient of a reflect-padded convolution): for each dimension up to two rules
-    // (output position, tap, extra input index): the B operand of (position, tap) additionally reads `extra`.
-    int adj;            // 0 = off
-    int ay_pos[2], ay_tap[2], ay_src[2];
-    int ax_pos[2], ax_tap[2], ax_src[2];
+    // reflect adjoint (data gradient of a reflect-padded convolution).  Per dimension the fold of the halo gradient
+    // is:  operand(pos == lo, tap K-1) += input[tap position - (K-1)]   and
+    //      operand(pos == hi, tap 0)   += input[tap position + (K-1)]      (-1 = rule absent)
+    int adj, ay_lo, ay_hi, ax_lo, ax_hi;
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -55,6 +54,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = Cfg<K, S>::NT;
     constexpr int MAXE = Cfg<K, S>::MAXE;
     constexpr int COT = 32 * MF;
+    constexpr int WV = COT / 4;                  // float4 per (tap, channel) weight row
+    constexpr int NWV = NT * CK * WV;            // float4 items of the weight slab
+    constexpr int WPT = (NWV + 255) / 256;
+    constexpr int NS = NT * (CK / 2);            // MFMA k-steps per chunk
     extern __shared__ float lds[];
 
     const int n = blockIdx.z;
@@ -74,13 +77,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int Cin = p.C0 + p.C1;
     const int HWin = p.Hin * p.Win;
 
-    // ---- gather offsets of this thread's staging elements (bits 0..19 spatial, 20..25 channel, 31 = zero)
+    // ---- byte offsets (within a frame, relative to the chunk's first channel) of this thread's staging elements;
+    //      negative = zero padding / outside the tile.  Reflection is resolved here, once per tile.
     int goff[MAXE];
     const int total = CK * plane;
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
         const int e = tid + i * 256;
-        int pk = (int)0x80000000;
+        int off = -1;
         if (e < total) {
             const int c = e / plane;
             const int rem = e - c * plane;
@@ -96,10 +100,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             } else {
                 ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
             }
-            if (ok) pk = (c << 20) | (gy * p.Win + gx);
-            else pk = (int)0x80000000 | (c << 20);
+            if (ok) off = (c * HWin + gy * p.Win + gx) * 4;
         }
-        goff[i] = pk;
+        goff[i] = off;
     }
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -113,23 +116,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
     const int aoff = lk * COT + li;
 
-    // reflect adjoint: LDS row / column of the extra input of each (fragment, rule), or -1
-    int ady[2][2], adx[2][2];
-    bool wave_adj = false;
+    // reflect adjoint: per-lane masks of the border positions this lane owns
+    float mxlo[2] = {0.f, 0.f}, mxhi[2] = {0.f, 0.f}, mylo[2] = {0.f, 0.f}, myhi[2] = {0.f, 0.f};
+    bool wave_x = false, wave_y = false;
     if constexpr (ADJ) {
-        bool any = false;
+        bool anyx = false, anyy = false;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int f = 2 * wave + q;
             const int oy = oy0 + f * FR + fy, ox = ox0 + fx;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                ady[q][r] = (oy == p.ay_pos[r]) ? (p.ay_src[r] - oy0 * S + p.pad_y) : -1;
-                adx[q][r] = (ox == p.ax_pos[r]) ? (p.ax_src[r] - ox0 * S + p.pad_x) : -1;
-                any = any || ady[q][r] >= 0 || adx[q][r] >= 0;
-            }
+            mxlo[q] = ox == p.ax_lo ? 1.f : 0.f;
+            mxhi[q] = ox == p.ax_hi ? 1.f : 0.f;
+            mylo[q] = oy == p.ay_lo ? 1.f : 0.f;
+            myhi[q] = oy == p.ay_hi ? 1.f : 0.f;
+            anyx = anyx || ox == p.ax_lo || ox == p.ax_hi;
+            anyy = anyy || oy == p.ay_lo || oy == p.ay_hi;
         }
-        wave_adj = __any(any);
+        wave_x = __any(anyx);
+        wave_y = __any(anyy);
     }
 
     f32x16 acc[MF][2];
@@ -140,107 +144,120 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
+    // Global -> register prefetch through buffer loads: out-of-range offsets (padding, channels beyond Cin, idle
+    // lanes) return 0 in hardware, so no select follows the load and the wait can sink to the LDS commit.
+    // A chunk never straddles the two concatenated sources (host checks C0 % CK == 0 when C1 > 0).
     const float* s0n = p.src0 + (size_t)n * p.C0 * HWin;
     const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HWin : nullptr;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HWin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(s1n != nullptr ? s1n : s0n), 0,
+                                                                         p.C1 * HWin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, NT * Cin * p.CoutP * 4, 0x00020000);
 
-    for (int cb = 0; cb < Cin; cb += CK) {
-        // ---- stage input chunk
+    float xr[MAXE];
+    f32x4 wr[WPT];
+    auto prefetch = [&](int cb) {
+        const bool first = cb < p.C0;
+        const int chan0 = (first ? cb : cb - p.C0) * HWin * 4;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < MAXE; ++i)
+                xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, goff[i] >= 0 ? goff[i] + chan0 : -1, 0, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXE; ++i)
+                xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, goff[i] >= 0 ? goff[i] + chan0 : -1, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * 256;
+            const int o4 = e % WV, tc = e / WV;
+            const int c = tc % CK, t = tc / CK;
+            const bool ok = e < NWV && cb + c < Cin;
+            const int off = ok ? (((t * Cin + cb + c) * p.CoutP + co0 + o4 * 4) * 4) : -1;
+            wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+        }
+    };
+    auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int e = tid + i * 256;
-            if (e < total) {
-                const int pk = goff[i];
-                const int cg = cb + ((pk >> 20) & 63);
-                float v = 0.f;
-                if (pk >= 0 && cg < Cin) {
-                    const float* s = cg < p.C0 ? s0n + (size_t)cg * HWin : s1n + (size_t)(cg - p.C0) * HWin;
-                    v = s[pk & 0xFFFFF];
+            if (e < total) Xl[e] = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < NWV) *reinterpret_cast<f32x4*>(Wl + (size_t)e * 4) = wr[i];
+        }
+    };
+
+    // operands of k-step s = (tap t, channel pair cp)
+    auto load_ops = [&](int s_, float (&a)[MF], float (&b)[2]) {
+        const int t = s_ / (CK / 2), cp = s_ % (CK / 2);
+        const int ky = t / K, kx = t % K;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) a[m] = Wl[(t * CK + 2 * cp) * COT + aoff + m * 32];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ad = boff[q] + 2 * cp * plane + ky * cols + kx;
+            float v = Xl[ad];
+            if constexpr (ADJ) {
+                // fold of the reflected halo: fixed offsets +-(K-1), always inside the staged tile
+                constexpr int D = K - 1;
+                const bool xl = kx == K - 1, xh = kx == 0, yl = ky == K - 1, yh = ky == 0;
+                if ((xl || xh) && wave_x) {
+                    const float mx = xl ? mxlo[q] : mxhi[q];
+                    v = fmaf(mx, Xl[ad + (xl ? -D : D)], v);
                 }
-                Xl[e] = v;
+                if ((yl || yh) && wave_y) {
+                    const float my = yl ? mylo[q] : myhi[q];
+                    const int dy = (yl ? -D : D) * cols;
+                    v = fmaf(my, Xl[ad + dy], v);
+                    if (xl || xh) {
+                        const float mx = xl ? mxlo[q] : mxhi[q];
+                        v = fmaf(my * mx, Xl[ad + dy + (xl ? -D : D)], v);
+                    }
+                }
             }
+            b[q] = v;
         }
-        // ---- stage weight slab [NT][CK][COT] (float4 along cout)
-        {
-            constexpr int V = COT / 4;
-            constexpr int NV = NT * CK * V;
-            for (int e = tid; e < NV; e += 256) {
-                const int o4 = e % V;
-                const int tc = e / V;
-                const int c = tc % CK, t = tc / CK;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cb + c < Cin)
-                    v = *reinterpret_cast<const f32x4*>(p.wpk + ((size_t)t * Cin + cb + c) * p.CoutP + co0 + o4 * 4);
-                *reinterpret_cast<f32x4*>(Wl + (size_t)tc * COT + o4 * 4) = v;
-            }
-        }
+    };
+
+    prefetch(0);
+    for (int cb = 0; cb < Cin; cb += CK) {
+        commit();
         __syncthreads();
-        // ---- MFMA
-        if (!ADJ || !wave_adj) {
+        if (cb + CK < Cin) prefetch(cb + CK);       // in flight during the MFMA loop
+        // ---- MFMA: per tap, operand reads software-pipelined one k-step ahead; a scheduling barrier per tap keeps
+        // the compiler from hoisting the whole chunk's LDS reads (register pressure -> occupancy)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int ky = t / K, kx = t % K;
-                const int bt = ky * cols + kx;
+        for (int t = 0; t < NT; ++t) {
+            constexpr int CP = CK / 2;
+            float a0[MF], b0[2], a1[MF], b1[2];
+            load_ops(t * CP, a0, b0);
 #pragma unroll
-                for (int cp = 0; cp < CK / 2; ++cp) {
-                    float a[MF], b[2];
+            for (int c2 = 0; c2 < CP; c2 += 2) {
+                // hipcc otherwise sinks the next step's ds_reads below these MFMAs and waits on them right away
+                if (c2 + 1 < CP) load_ops(t * CP + c2 + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < MF; ++m) a[m] = Wl[(t * CK + 2 * cp) * COT + aoff + m * 32];
+                for (int m = 0; m < MF; ++m)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) b[q] = Xl[boff[q] + 2 * cp * plane + bt];
-#pragma unroll
-                    for (int m = 0; m < MF; ++m)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
-                }
-            }
-        } else {
-            // waves that own border positions: B(position, tap) = sum over {normal, extra row} x {normal, extra col};
-            // branch-free (unused extras read the normal address with weight 0); tap loop kept rolled to bound registers
-#pragma unroll 1
-            for (int t = 0; t < NT; ++t) {
-                const int ky = t / K, kx = t % K;
-                const int bt = ky * cols + kx;
-                int o_r[2], o_c[2], o_rc[2];
-                float m_r[2], m_c[2], m_rc[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int f = 2 * wave + q;
-                    int ey = -1, ex = -1;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        if (p.ay_tap[r] == ky && ady[q][r] >= 0) ey = ady[q][r];
-                        if (p.ax_tap[r] == kx && adx[q][r] >= 0) ex = adx[q][r];
-                    }
-                    const int nrow = (f * FR + fy) * S + ky, ncol = fx * S + kx;
-                    const int base = lk * plane;
-                    o_r[q] = base + (ey >= 0 ? ey : nrow) * cols + ncol;
-                    o_c[q] = base + nrow * cols + (ex >= 0 ? ex : ncol);
-                    o_rc[q] = base + (ey >= 0 ? ey : nrow) * cols + (ex >= 0 ? ex : ncol);
-                    m_r[q] = ey >= 0 ? 1.f : 0.f;
-                    m_c[q] = ex >= 0 ? 1.f : 0.f;
-                    m_rc[q] = (ey >= 0 && ex >= 0) ? 1.f : 0.f;
-                }
-#pragma unroll
-                for (int cp = 0; cp < CK / 2; ++cp) {
-                    float a[MF], b[2];
-#pragma unroll
-                    for (int m = 0; m < MF; ++m) a[m] = Wl[(t * CK + 2 * cp) * COT + aoff + m * 32];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        float v = Xl[boff[q] + 2 * cp * plane + bt];
-                        v = fmaf(m_r[q], Xl[o_r[q] + 2 * cp * plane], v);
-                        v = fmaf(m_c[q], Xl[o_c[q] + 2 * cp * plane], v);
-                        v = fmaf(m_rc[q], Xl[o_rc[q] + 2 * cp * plane], v);
-                        b[q] = v;
-                    }
+                    for (int q = 0; q < 2; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[q], acc[m][q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c2 + 2 < CP) load_ops(t * CP + c2 + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c2 + 1 < CP) {
 #pragma unroll
                     for (int m = 0; m < MF; ++m)
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[q], acc[m][q], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -327,6 +344,8 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
     C2S_REQUIRE(d->N > 0 && d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0 || src1), "conv_igemm: bad channels");
     C2S_REQUIRE(d->CoutP % 32 == 0 && d->CoutP >= d->Cout && d->Cout > 0, "conv_igemm: CoutP must be a multiple of 32");
     C2S_REQUIRE(d->KH == d->KW, "conv_igemm: square kernels only");
+    C2S_REQUIRE(d->C1 == 0 || d->C0 % 16 == 0, "conv_igemm: with two sources C0 must be a multiple of 16");
+    C2S_REQUIRE((long)(d->C0 > d->C1 ? d->C0 : d->C1) * d->Hin * d->Win * 4 < (1L << 31), "conv_igemm: frame too large");
     C2S_REQUIRE((long)d->Hin * d->Win < (1 << 20), "conv_igemm: input plane too large");
     C2S_REQUIRE(d->Hout > 0 && d->Wout > 0, "conv_igemm: empty output");
     C2S_REQUIRE((d->Hout - 1) * d->osy + d->ooy < d->OutH && (d->Wout - 1) * d->osx + d->oox < d->OutW,
@@ -340,24 +359,22 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
     p.pad_y = d->pad_y; p.pad_x = d->pad_x; p.pad_mode = d->pad_mode;
     p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox; p.accumulate = d->accumulate;
     p.adj = d->reflect_adjoint;
-    for (int r = 0; r < 2; ++r) { p.ay_pos[r] = p.ax_pos[r] = -1; p.ay_tap[r] = p.ax_tap[r] = -1; p.ay_src[r] = p.ax_src[r] = 0; }
+    p.ay_lo = p.ay_hi = p.ax_lo = p.ax_hi = -1;
     if (d->reflect_adjoint) {
         C2S_REQUIRE(d->pad_mode == C2S_PAD_ZEROS && d->S == 1 && (d->KH == 3 || d->KH == 2),
                     "conv_igemm: reflect_adjoint applies to the zero-padded 3x3 / 2x2-parity data-gradient launches");
         C2S_REQUIRE(d->Hin >= 2 && d->Win >= 2 && d->Hin != 3 && d->Win != 3, "conv_igemm: reflect_adjoint needs planes of 2 or >= 4");
         if (d->KH == 3) {
-            // dgrad of conv3x3(reflect pad 1): g_x[1] += w[0] g_y[0] ; g_x[H-2] += w[2] g_y[H-1]  (flipped taps 2 / 0)
+            // dgrad of conv3x3(reflect pad 1): g_x[1] += w[0] g_y[0] ; g_x[H-2] += w[2] g_y[H-1]
+            // (flipped taps: position 1 / tap 2 reads input 0 = tap position - 2; position H-2 / tap 0 reads H-1 = +2)
             C2S_REQUIRE(d->pad_y == 1 && d->pad_x == 1 && d->Hin == d->Hout && d->Win == d->Wout, "conv_igemm: bad 3x3 adjoint geometry");
-            p.ay_pos[0] = 1; p.ay_tap[0] = 2; p.ay_src[0] = 0;
-            p.ay_pos[1] = d->Hout - 2; p.ay_tap[1] = 0; p.ay_src[1] = d->Hin - 1;
-            p.ax_pos[0] = 1; p.ax_tap[0] = 2; p.ax_src[0] = 0;
-            p.ax_pos[1] = d->Wout - 2; p.ax_tap[1] = 0; p.ax_src[1] = d->Win - 1;
+            p.ay_lo = 1; p.ay_hi = d->Hout - 2;
+            p.ax_lo = 1; p.ax_hi = d->Wout - 2;
         } else {
-            // parity sub-kernel of the dgrad of conv4x4s2(reflect pad 1); parity = 1 - pad
-            if (d->pad_y == 0) { p.ay_pos[0] = 0; p.ay_tap[0] = 1; p.ay_src[0] = 0; }
-            else { p.ay_pos[0] = d->Hout - 1; p.ay_tap[0] = 0; p.ay_src[0] = d->Hin - 1; }
-            if (d->pad_x == 0) { p.ax_pos[0] = 0; p.ax_tap[0] = 1; p.ax_src[0] = 0; }
-            else { p.ax_pos[0] = d->Wout - 1; p.ax_tap[0] = 0; p.ax_src[0] = d->Win - 1; }
+            // parity sub-kernel of the dgrad of conv4x4s2(reflect pad 1); parity = 1 - pad:
+            // parity 1 (pad 0): position 0 / tap 1 additionally reads input 0; parity 0 (pad 1): position Ho-1 / tap 0 reads Ho-1
+            if (d->pad_y == 0) p.ay_lo = 0; else p.ay_hi = d->Hout - 1;
+            if (d->pad_x == 0) p.ax_lo = 0; else p.ax_hi = d->Wout - 1;
         }
     }
     int l2 = 5;
