@@ -272,35 +272,38 @@ __global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restri
     }
 }
 
-// per channel: dgamma, dbeta (sum over frames)
-__global__ void norm_bwd_param_kernel(const float* __restrict__ rowsum, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, const int* __restrict__ valid, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// per channel: dgamma, dbeta (sum over frames); one wave per channel, lanes over frames
+__global__ __launch_bounds__(64) void norm_bwd_param_kernel(const float* __restrict__ rowsum, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, const int* __restrict__ valid,
+                                                            int N, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double dg = 0, db = 0;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         if (valid != nullptr && valid[n] == 0) continue;
         const long row = (long)n * C + c;
         dg += rowsum[row * 3 + 1];
         db += rowsum[row * 3];
     }
-    if (dgamma != nullptr) dgamma[c] = (float)dg;
-    if (dbeta != nullptr) dbeta[c] = (float)db;
+    for (int o = 32; o > 0; o >>= 1) { dg += __shfl_xor(dg, o, 64); db += __shfl_xor(db, o, 64); }
+    if (lane == 0) {
+        if (dgamma != nullptr) dgamma[c] = (float)dg;
+        if (dbeta != nullptr) dbeta[c] = (float)db;
+    }
 }
 
 // gradient of the producing convolution's bias: per-channel sum of dx, from the per-(row,segment) partials the
-// apply pass leaves in part[item*3]
-__global__ void norm_bwd_dbias_kernel(const float* __restrict__ part, float* __restrict__ dbias,
-                                      const int* __restrict__ valid, int N, int C, int segs) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// apply pass leaves in part[item*3]; one wave per channel, lanes over (frame, segment)
+__global__ __launch_bounds__(64) void norm_bwd_dbias_kernel(const float* __restrict__ part, float* __restrict__ dbias,
+                                                            const int* __restrict__ valid, int N, int C, int segs) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s = 0;
-    for (int n = 0; n < N; ++n) {
+    for (int it = lane; it < N * segs; it += 64) {
+        const int n = it / segs, k = it - n * segs;
         if (valid != nullptr && valid[n] == 0) continue;
-        const long row = (long)n * C + c;
-        for (int k = 0; k < segs; ++k) s += part[(row * segs + k) * 3];
+        s += part[(((long)n * C + c) * segs + k) * 3];
     }
-    dbias[c] = (float)s;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) dbias[c] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
@@ -428,14 +431,14 @@ extern "C" int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float*
     const int ngroups = d->kind == C2S_NORM_BATCH ? d->C : d->N * d->groups;
     hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3(ngroups), dim3(64), 0, st, rowsum, gamma, group_stats, rowk, valid, *d);
     C2S_CHECK_LAUNCH("norm_bwd_coef");
-    hipLaunchKernelGGL(norm_bwd_param_kernel, dim3(cdiv(d->C, 64)), dim3(64), 0, st, rowsum, dgamma, dbeta, valid, d->N,
+    hipLaunchKernelGGL(norm_bwd_param_kernel, dim3(d->C), dim3(64), 0, st, rowsum, dgamma, dbeta, valid, d->N,
                        d->C);
     C2S_CHECK_LAUNCH("norm_bwd_param");
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(cdiv(nitems, 4)), dim3(256), 0, st, x, g, row_ab, rowk, gx, part, valid,
                        d->C, d->HW, segs, nitems, relu);
     C2S_CHECK_LAUNCH("norm_bwd_apply");
     if (dbias != nullptr) {
-        hipLaunchKernelGGL(norm_bwd_dbias_kernel, dim3(cdiv(d->C, 64)), dim3(64), 0, st, part, dbias, valid, d->N, d->C,
+        hipLaunchKernelGGL(norm_bwd_dbias_kernel, dim3(d->C), dim3(64), 0, st, part, dbias, valid, d->N, d->C,
                            segs);
         C2S_CHECK_LAUNCH("norm_bwd_dbias");
     }

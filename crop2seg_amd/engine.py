@@ -172,7 +172,7 @@ def _wgrad_slices(ctx: Ctx, N: int, Hout: int, Wout: int, S: int, cin: int, cout
     PC = 1 << l2
     ntiles = N * ((Wout + PC - 1) // PC) * ((Hout + TP // PC - 1) // (TP // PC))
     blocks = ((cin + 31) // 32) * ((cout + 63) // 64)
-    return max(1, min(ntiles, (4 * ctx.cus) // blocks))
+    return max(1, min(ntiles, (2 * ctx.cus) // blocks))     # 2 resident workgroups per CU
 
 
 def _wgrad(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int, Wout: int, K: int, S: int, pad: int,
