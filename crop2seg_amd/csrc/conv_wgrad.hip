@@ -167,9 +167,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // tile (32*S floats + 1 halo column each side) and of the gout tile (32 floats) is 128-byte aligned: global
 // traffic is float4, and the loads of tile i+1 are issued into registers BEFORE the MFMA loop of tile i
 // (register-staged software pipeline, cdna_hip_programming.md T14): HBM/L2 latency hides under ~20k cycles of MFMA.
+constexpr int FAST_TP = 128;  // positions per tile of the fast path (4 rows x 32)
+
 template <int K, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
-    constexpr int TP = (S == 2) ? 64 : 128;
+    constexpr int TP = FAST_TP;
     constexpr int PR = TP / 32;                    // tile rows
     constexpr int NT = K * K, TH = (NT + 1) / 2;
     constexpr int PAD = (K == 1) ? 0 : 1;
@@ -320,19 +322,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
         __syncthreads();
         const int nxt = next_tile(tile + p.nslices);
         if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
-#pragma unroll 4
-        for (int kk = 0; kk < TP / 2; ++kk) {
+        // operand reads software-pipelined one position-pair ahead of the MFMAs (order pinned with sched barriers)
+        auto load_ops = [&](int kk, float (&a)[TH], float& b) {
             const int q = 2 * kk + lk;
             const int qy = q >> 5, qx = q & 31;
-            const float b = Gl[(ofrag * 32 + li) * (TP + 1) + q];
+            b = Gl[(ofrag * 32 + li) * (TP + 1) + q];
             const int abase = li * PLANEP + (qy * S) * XC + qx * S;
 #pragma unroll
-            for (int i = 0; i < TH; ++i) {
-                if (2 * i + thalf < NT) {
-                    const float a = Xl[abase + toff[i]];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-                }
-            }
+            for (int i = 0; i < TH; ++i) a[i] = (2 * i + thalf < NT) ? Xl[abase + toff[i]] : 0.f;
+        };
+        float a0[TH], a1[TH], b0, b1;
+        load_ops(0, a0, b0);
+#pragma unroll 2
+        for (int kk = 0; kk < TP / 2; kk += 2) {
+            load_ops(kk + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TH; ++i)
+                if (2 * i + thalf < NT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ops(kk + 2 < TP / 2 ? kk + 2 : kk, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TH; ++i)
+                if (2 * i + thalf < NT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         tile = nxt;
@@ -383,7 +397,7 @@ void geometry(const c2s_wgrad_desc* d, int TP, int* log2pc, int* tiles_x, int* t
 
 template <int K, int S>
 int launch_wgrad_fast(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
-    constexpr int TP = (S == 2) ? 64 : 128, PR = TP / 32;
+    constexpr int TP = FAST_TP, PR = TP / 32;
     constexpr int XR = (PR - 1) * S + K, XC = 31 * S + K;
     p.log2pc = 5;
     p.tiles_x = d->Wout / 32;
@@ -406,7 +420,7 @@ template <int K, int S>
 int launch_wgrad(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
     using C = WCfg<K, S>;
     {   // fast path: 32-wide aligned tiles
-        constexpr int PR = C::TP / 32;
+        constexpr int PR = FAST_TP / 32;
         const int pad = (K == 1) ? 0 : 1;
         if (d->Wout % 32 == 0 && d->Win == d->Wout * S && d->Hin == d->Hout * S && d->Hout % PR == 0 &&
             d->pad_y == pad && d->pad_x == pad && d->Win % 4 == 0)
