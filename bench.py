@@ -29,6 +29,11 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X dense fp32 MFMA/vector peak (MI355X_MICROARCH.md, chip-level parameters)
+# HBM bytes of ONE launch of the dominant kernel (64->64 3x3 @128x128, N=128): rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate passes (profiles/r01_pmc_conv3x3_64x64_128px.csv): 822,877 KiB + 524,288 KiB.
+# FETCH_SIZE is quoted uncorrected: the x2 correction of the micro-architecture guide is calibrated for 16-B/lane
+# streaming reads, this kernel gathers 4 B/lane.  Algorithmic bytes: 537 MB in + 537 MB out + 0.15 MB weights.
+DOMINANT_KERNEL_TRAFFIC_BYTES = (822876.8 + 524288.0) * 1024
 
 
 def synthetic_batch(B, T, H, W, seed, device, n_classes=15):
@@ -159,8 +164,9 @@ def main():
                                    f"random-init weight_init weights, BASELINE.json configs[1] shape in fp32",
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
-                         "kernel": "conv_igemm_kernel<3,1,2> 64->64 3x3 reflect @128x128 (fwd + dgrad launches)",
+                         "frac": achieved / PEAK_F32_TFLOPS,
+                         "traffic": DOMINANT_KERNEL_TRAFFIC_BYTES if (B * T == 128 and H == 128) else None,
+                         "kernel": "conv_igemm_kernel<3,1,2,*> 64->64 3x3 reflect @128x128 (forward + data-gradient launches)",
                          "launches_timed": len(ms), "avg_launch_ms": kernel_ms,
                          "algorithmic_flops_per_launch": flops_launch},
             "loss": loss_val,

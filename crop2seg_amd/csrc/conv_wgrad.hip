@@ -381,8 +381,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
     const int c = (int)(tc % Cin), t = (int)(tc / Cin);
     const size_t stride = (size_t)NT * CinP * CoutB;
     const float* s = slabs + ((size_t)t * CinP + c) * CoutB + o;
-    float acc = 0.f;
-    for (int k = 0; k < nslices; ++k) acc += s[(size_t)k * stride];
+    // 8 independent partial sums keep 8 loads in flight (the slices are 100+ KB apart: latency-bound otherwise);
+    // the combination order is fixed, so the result stays bitwise reproducible
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nslices; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] += s[(size_t)(k + u) * stride];
+    }
+    for (int u = 0; k < nslices; ++k, ++u) part[u] += s[(size_t)k * stride];
+    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     float* d = dst + o * so + c * sc + tt.off[t];
     *d = accumulate ? *d + acc : acc;
 }
