@@ -43,13 +43,22 @@ __device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_t
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// Workgroup = 16 adjacent pixels x 16 "slots".  The slot means something different in each phase so that every
+// x element is loaded by exactly one thread per phase (no 16-fold redundant loads, 768 loads per thread in total):
+//   1 stats   : slot = GroupNorm group          (loop t, c in group)
+//   2 scores  : slot = time slice t % 16        (loop c; 16 head accumulators; U through the scalar cache)
+//   3 softmax : slot = head                     (loop t over LDS)
+//   4 z       : slot = channel slice c % 16     (loop t; 16 head accumulators) -> LDS, half of the channels at a time
+//   5 emb     : slot = head                     (loop c over LDS; Wc rows from L1/L2)
 __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     extern __shared__ float lds[];
     const int C = p.C, T = p.T, HW = p.HW;
-    float* Ul = lds;              // [16][C]
-    float* ABl = Ul + NH * C;     // [C][16][2]
-    float* Sl = ABl + C * 32;     // [T][16][16]
-    const int tid = threadIdx.x, px = tid & 15, hh = tid >> 4;
+    const int CH = C > 64 ? C / 2 : C;          // channels per z/emb pass
+    float* ABl = lds;                           // [C][16][2]   per-(channel,pixel) scale / shift of the GroupNorm
+    float* Sl = ABl + C * 32;                   // [T][16][16]  scores -> attention (post-dropout)
+    float* ASl = Sl + T * 256;                  // [16][16]     sum_t attention
+    float* Zl = ASl + 256;                      // [16][CH][16] z = sum_t attn * xhat
+    const int tid = threadIdx.x, px = tid & 15, slot = tid >> 4;
     const int tiles_per_b = (HW + 15) / 16;
     const int b = blockIdx.x / tiles_per_b;
     const int pix_raw = (blockIdx.x % tiles_per_b) * 16 + px;
@@ -57,29 +66,32 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     const int pix = act ? pix_raw : HW - 1;
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
-    for (int i = tid; i < NH * C; i += 256) Ul[i] = p.U[i];
     const float* xb = p.x + (size_t)b * T * C * HW + pix;
 
-    // ---- phase 1: GroupNorm statistics of group hh (padded frames included, tae.py:461)
+    // ---- phase 1: GroupNorm statistics of group `slot` (padded frames included, tae.py:461); one pass, shifted
     {
-        float s = 0.f;
-        for (int t = 0; t < T; ++t)
-            for (int cc = 0; cc < cpg; ++cc) s += xb[(size_t)(t * C + hh * cpg + cc) * HW];
-        const float inv_n = 1.f / (float)(cpg * T);
-        const float mean = s * inv_n;
-        float m2 = 0.f;
-        for (int t = 0; t < T; ++t)
+        const int g = slot;
+        const float K0 = xb[(size_t)(g * cpg) * HW];
+        float s = 0.f, ss = 0.f;
+        for (int t = 0; t < T; ++t) {
+#pragma unroll 8
             for (int cc = 0; cc < cpg; ++cc) {
-                const float d = xb[(size_t)(t * C + hh * cpg + cc) * HW] - mean;
-                m2 += d * d;
+                const float d = xb[(size_t)(t * C + g * cpg + cc) * HW] - K0;
+                s += d;
+                ss += d * d;
             }
-        const float rstd = rsqrtf(m2 * inv_n + p.eps);
+        }
+        const float inv_n = 1.f / (float)(cpg * T);
+        const float md = s * inv_n;
+        const float mean = K0 + md;
+        const float var = fmaxf(ss * inv_n - md * md, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
         if (act) {
-            p.stats[(pidx * NH + hh) * 2] = mean;
-            p.stats[(pidx * NH + hh) * 2 + 1] = rstd;
+            p.stats[(pidx * NH + g) * 2] = mean;
+            p.stats[(pidx * NH + g) * 2 + 1] = rstd;
         }
         for (int cc = 0; cc < cpg; ++cc) {
-            const int c = hh * cpg + cc;
+            const int c = g * cpg + cc;
             const float a = p.gamma[c] * rstd;
             ABl[(c * 16 + px) * 2] = a;
             ABl[(c * 16 + px) * 2 + 1] = p.beta[c] - mean * a;
@@ -87,63 +99,99 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     }
     __syncthreads();
 
-    // ---- phase 2: scores of head hh, masking, softmax over T, dropout
-    float mx = -3.0e38f;
-    for (int t = 0; t < T; ++t) {
-        float s = p.s0[(b * T + t) * NH + hh];
+    // ---- phase 2: scores.  U[h][c] is wave-uniform: it comes through the scalar cache, not LDS.
+    for (int t = slot; t < T; t += 16) {
+        float sc[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) sc[h] = p.s0[(b * T + t) * NH + h];
         const float* xt = xb + (size_t)t * C * HW;
-#pragma unroll 8
+#pragma unroll 4
         for (int c = 0; c < C; ++c) {
-            const float xv = xt[(size_t)c * HW];
-            s += Ul[hh * C + c] * (ABl[(c * 16 + px) * 2] * xv + ABl[(c * 16 + px) * 2 + 1]);
+            const float xh = ABl[(c * 16 + px) * 2] * xt[(size_t)c * HW] + ABl[(c * 16 + px) * 2 + 1];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) sc[h] = fmaf(p.U[h * C + c], xh, sc[h]);
         }
-        if (p.valid != nullptr && p.valid[b * T + t] == 0) s = -1e6f;   // tae.py:831
-        Sl[(t * 16 + hh) * 16 + px] = s;
-        mx = fmaxf(mx, s);
+        const bool padded = p.valid != nullptr && p.valid[b * T + t] == 0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) Sl[(t * 16 + h) * 16 + px] = padded ? -1e6f : sc[h];   // tae.py:831
     }
-    float den = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float e = __expf(Sl[(t * 16 + hh) * 16 + px] - mx);
-        Sl[(t * 16 + hh) * 16 + px] = e;
-        den += e;
-    }
-    const float inv_den = 1.f / den;
-    float asum = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float a = Sl[(t * 16 + hh) * 16 + px] * inv_den;
-        const float ad = a * keep_scale(p, hh, Ptot, pidx, t);
-        const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
-        if (act) {
-            if (p.attn_pre != nullptr) p.attn_pre[o] = a;
-            p.attn[o] = ad;
+    __syncthreads();
+
+    // ---- phase 3: softmax over T for head `slot`, dropout
+    {
+        const int hh = slot;
+        float mx = -3.0e38f;
+        for (int t = 0; t < T; ++t) mx = fmaxf(mx, Sl[(t * 16 + hh) * 16 + px]);
+        float den = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float e = __expf(Sl[(t * 16 + hh) * 16 + px] - mx);
+            Sl[(t * 16 + hh) * 16 + px] = e;
+            den += e;
         }
-        Sl[(t * 16 + hh) * 16 + px] = ad;
-        asum += ad;
+        const float inv_den = 1.f / den;
+        float asum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float a = Sl[(t * 16 + hh) * 16 + px] * inv_den;
+            const float ad = a * keep_scale(p, hh, Ptot, pidx, t);
+            const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
+            if (act) {
+                if (p.attn_pre != nullptr) p.attn_pre[o] = a;
+                p.attn[o] = ad;
+            }
+            Sl[(t * 16 + hh) * 16 + px] = ad;
+            asum += ad;
+        }
+        ASl[hh * 16 + px] = asum;
     }
     if (p.emb == nullptr) return;   // W-TAE: attention masks only (tae.py:619)
+    __syncthreads();
 
-    // ---- phase 3: z = sum_t attn * xhat ; emb slice of head hh
+    // ---- phases 4+5, CH channels at a time
     float o[DV];
 #pragma unroll
     for (int j = 0; j < DV; ++j) o[j] = 0.f;
-    for (int c = 0; c < C; ++c) {
-        float z = 0.f;
-#pragma unroll 4
-        for (int t = 0; t < T; ++t) z += Sl[(t * 16 + hh) * 16 + px] * xb[(size_t)(t * C + c) * HW];
-        const float zz = ABl[(c * 16 + px) * 2] * z + ABl[(c * 16 + px) * 2 + 1] * asum;
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        // 4: z[h] = sum_t attn[h,t] * x[t,c] for the channels c = c0 + slot, c0 + slot + 16, ...
+        for (int c = c0 + slot; c < c0 + CH; c += 16) {
+            float z[NH];
 #pragma unroll
-        for (int j = 0; j < DV; ++j) o[j] += p.Wc[(size_t)(hh * DV + j) * C + c] * zz;
+            for (int h = 0; h < NH; ++h) z[h] = 0.f;
+#pragma unroll 2
+            for (int t = 0; t < T; ++t) {
+                const float xv = xb[(size_t)(t * C + c) * HW];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) z[h] = fmaf(Sl[(t * 16 + h) * 16 + px], xv, z[h]);
+            }
+            const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) Zl[(h * CH + (c - c0)) * 16 + px] = a * z[h] + bb * ASl[h * 16 + px];
+        }
+        __syncthreads();
+        // 5: emb slice of head `slot`
+        {
+            const int hh = slot;
+            for (int c = 0; c < CH; ++c) {
+                const float zz = Zl[(hh * CH + c) * 16 + px];
+#pragma unroll
+                for (int j = 0; j < DV; ++j) o[j] = fmaf(p.Wc[(size_t)(hh * DV + j) * C + c0 + c], zz, o[j]);
+            }
+        }
+        __syncthreads();
     }
+    {
+        const int hh = slot;
+        const float asum = ASl[hh * 16 + px];
 #pragma unroll
-    for (int j = 0; j < DV; ++j) o[j] += asum * p.bc[hh * DV + j];
-    for (int t = 0; t < T; ++t) {
-        const float ad = Sl[(t * 16 + hh) * 16 + px];
+        for (int j = 0; j < DV; ++j) o[j] += asum * p.bc[hh * DV + j];
+        for (int t = 0; t < T; ++t) {
+            const float ad = Sl[(t * 16 + hh) * 16 + px];
 #pragma unroll
-        for (int j = 0; j < DV; ++j) o[j] += ad * p.pe[(b * T + t) * DV + j];
-    }
-    if (act) {
+            for (int j = 0; j < DV; ++j) o[j] = fmaf(ad, p.pe[(b * T + t) * DV + j], o[j]);
+        }
+        if (act) {
 #pragma unroll
-        for (int j = 0; j < DV; ++j) p.emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] = o[j];
+            for (int j = 0; j < DV; ++j) p.emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] = o[j];
+        }
     }
 }
 
@@ -464,7 +512,10 @@ __global__ void dropout_nchw_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
-size_t fwd_lds(const c2s_ltae_desc* d) { return ((size_t)NH * d->C + (size_t)d->C * 32 + (size_t)d->T * 256) * 4; }
+size_t fwd_lds(const c2s_ltae_desc* d) {
+    const size_t CH = d->C > 64 ? d->C / 2 : d->C;
+    return ((size_t)d->C * 32 + (size_t)d->T * 256 + 256 + NH * CH * 16) * 4;
+}
 size_t bwd1_lds(const c2s_ltae_desc* d) { return ((size_t)d->C * 32 + (size_t)d->T * 512) * 4; }
 size_t bwd2_lds(const c2s_ltae_desc* d) { return ((size_t)NH * d->C + 256 * 16 + (size_t)d->T * 512) * 4; }
 
