@@ -196,184 +196,251 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward, part 1
-// thread = (pixel, head): softmax/dropout backward -> GS (d score), V = sum_t gs xhat, Z = sum_t attn xhat,
-// per-tile partials of d s0 and d bc.
+// Softmax/dropout backward -> GS (d score), V = sum_t gs xhat, Z = sum_t attn xhat, per-tile partials of d s0 and
+// d bc.  Workgroup = PT adjacent pixels x S = 256/PT slots (PT = 16 for T <= 32, 8 for longer series so that the
+// [T][16][PT] tiles fit in LDS); like the forward kernel the slot changes meaning per phase:
+//   A1 r[h][c] = sum_j ge[16h+j] Wc[16h+j][c]   slot -> (h, c) items          (RC channels at a time)
+//   A2 dot[h,t] += r[h][c] xhat[t,c]            slot = time slice
+//   B  softmax / dropout backward               slot = head
+//   C  V, Z                                     slot = channel slice
+template <int PT>
 __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
+    constexpr int S = 256 / PT;
+    constexpr int RC = 32;                       // channels per r-chunk
     extern __shared__ float lds[];
     const int C = p.C, T = p.T, HW = p.HW;
-    float* ABl = lds;             // [C][16][2]
-    float* Dl = ABl + C * 32;     // [T][16][16]  dot -> ga -> gs
-    float* Al = Dl + T * 256;     // [T][16][16]  attn (post-dropout)
-    const int tid = threadIdx.x, px = tid & 15, hh = tid >> 4;
-    const int tiles_per_b = (HW + 15) / 16;
-    const int b = blockIdx.x / tiles_per_b;
-    const int pix_raw = (blockIdx.x % tiles_per_b) * 16 + px;
-    const bool act = pix_raw < HW;
+    float* ABl = lds;                            // [C][PT][2]
+    float* GEl = ABl + C * PT * 2;               // [256][PT]
+    float* Rl = GEl + 256 * PT;                  // [16][RC][PT]
+    float* Dl = Rl + NH * RC * PT;               // [T][16][PT]  dot -> ga -> gs
+    float* Al = Dl + T * NH * PT;                // [T][16][PT]  attention (post-dropout)
+    float* SUMl = Al + T * NH * PT;              // [2][16][PT]  sum_t attn, sum_t gs
+    const int tid = threadIdx.x, px = tid % PT, slot = tid / PT;
+    const int tiles_per_b = (HW + PT - 1) / PT;
+    const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * PT;
+    const bool act = pix0 + px < HW;
     const float actf = act ? 1.f : 0.f;
-    const int pix = act ? pix_raw : HW - 1;
+    const int pix = act ? pix0 + px : HW - 1;
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
     const float* xb = p.x + (size_t)b * T * C * HW + pix;
-    {
-        const float mean = p.stats_in[(pidx * NH + hh) * 2], rstd = p.stats_in[(pidx * NH + hh) * 2 + 1];
+
+    for (int g = slot; g < NH; g += S) {
+        const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
         for (int cc = 0; cc < cpg; ++cc) {
-            const int c = hh * cpg + cc;
+            const int c = g * cpg + cc;
             const float a = p.gamma[c] * rstd;
-            ABl[(c * 16 + px) * 2] = a;
-            ABl[(c * 16 + px) * 2 + 1] = p.beta[c] - mean * a;
+            ABl[(c * PT + px) * 2] = a;
+            ABl[(c * PT + px) * 2 + 1] = p.beta[c] - mean * a;
         }
     }
-    float ge[DV];
-    float gebc = 0.f;
-#pragma unroll
-    for (int j = 0; j < DV; ++j) {
-        ge[j] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] : 0.f;
-        gebc += ge[j] * p.bc[hh * DV + j];
-    }
-    for (int t = 0; t < T; ++t) {
-        Dl[(t * 16 + hh) * 16 + px] = 0.f;
-        Al[(t * 16 + hh) * 16 + px] = p.attn_in[((size_t)(hh * p.B + b) * T + t) * HW + pix];
+    for (int ch = slot; ch < NH * DV; ch += S)
+        GEl[ch * PT + px] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + ch) * HW + pix] : 0.f;
+    for (int i = slot; i < T * NH; i += S) {
+        const int t = i / NH, h = i % NH;
+        Dl[i * PT + px] = 0.f;
+        Al[i * PT + px] = p.attn_in[((size_t)(h * p.B + b) * T + t) * HW + pix];
     }
     __syncthreads();
-    // dot[t] = sum_c r_c * xhat[t,c],  r_c = sum_j ge[j] Wc[16h+j][c]
+
     if (p.g_emb != nullptr) {
-        for (int c = 0; c < C; ++c) {
-            float r = 0.f;
+        for (int c0 = 0; c0 < C; c0 += RC) {
+            // A1
+            for (int it = slot; it < NH * RC; it += S) {
+                const int h = it / RC, cc = it % RC;
+                float r = 0.f;
 #pragma unroll
-            for (int j = 0; j < DV; ++j) r += ge[j] * p.Wc[(size_t)(hh * DV + j) * C + c];
-            const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
-#pragma unroll 4
-            for (int t = 0; t < T; ++t) Dl[(t * 16 + hh) * 16 + px] += r * (a * xb[(size_t)(t * C + c) * HW] + bb);
+                for (int j = 0; j < DV; ++j) r = fmaf(GEl[(h * DV + j) * PT + px], p.Wc[(size_t)(h * DV + j) * C + c0 + cc], r);
+                Rl[it * PT + px] = r;
+            }
+            __syncthreads();
+            // A2
+            for (int t = slot; t < T; t += S) {
+                float acc[NH];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc[h] = 0.f;
+                const float* xt = xb + (size_t)t * C * HW;
+#pragma unroll 2
+                for (int cc = 0; cc < RC; ++cc) {
+                    const int c = c0 + cc;
+                    const float xh = ABl[(c * PT + px) * 2] * xt[(size_t)c * HW] + ABl[(c * PT + px) * 2 + 1];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) acc[h] = fmaf(Rl[(h * RC + cc) * PT + px], xh, acc[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < NH; ++h) Dl[(t * NH + h) * PT + px] += acc[h];
+            }
+            __syncthreads();
         }
     }
-    // softmax / dropout backward
-    float dsum = 0.f, asum = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
-        float gap = Dl[(t * 16 + hh) * 16 + px] + gebc;
-        if (p.g_attn != nullptr) gap += p.g_attn[o];
+
+    // B: head = slot
+    if (slot < NH) {
+        const int hh = slot;
+        float ge[DV];
+        float gebc = 0.f;
 #pragma unroll
-        for (int j = 0; j < DV; ++j) gap += ge[j] * p.pe[(b * T + t) * DV + j];
-        const float ga = gap * keep_scale(p, hh, Ptot, pidx, t);
-        dsum += p.attn_pre_in[o] * ga;
-        Dl[(t * 16 + hh) * 16 + px] = ga;
-        asum += Al[(t * 16 + hh) * 16 + px];
-    }
-    for (int t = 0; t < T; ++t) {
-        const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
-        const float gs = p.attn_pre_in[o] * (Dl[(t * 16 + hh) * 16 + px] - dsum);
-        Dl[(t * 16 + hh) * 16 + px] = gs;
-        if (act) p.GS[o] = gs;
-        // d s0[b,t,h]: sum over the 16 pixels of the tile
-        float r = gs * actf;
-        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
-        if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + hh] = r;
-    }
+        for (int j = 0; j < DV; ++j) {
+            ge[j] = GEl[(hh * DV + j) * PT + px];
+            gebc = fmaf(ge[j], p.bc[hh * DV + j], gebc);
+        }
+        float dsum = 0.f, asum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
+            float gap = Dl[(t * NH + hh) * PT + px] + gebc;
+            if (p.g_attn != nullptr) gap += p.g_attn[o];
 #pragma unroll
-    for (int j = 0; j < DV; ++j) {
-        float r = ge[j] * asum * actf;
-        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
-        if (px == 0) p.part_bc[(size_t)blockIdx.x * NH * DV + hh * DV + j] = r;
+            for (int j = 0; j < DV; ++j) gap = fmaf(ge[j], p.pe[(b * T + t) * DV + j], gap);
+            const float ga = gap * keep_scale(p, hh, Ptot, pidx, t);
+            dsum = fmaf(p.attn_pre_in[o], ga, dsum);
+            Dl[(t * NH + hh) * PT + px] = ga;
+            asum += Al[(t * NH + hh) * PT + px];
+        }
+        float gssum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
+            const float gs = p.attn_pre_in[o] * (Dl[(t * NH + hh) * PT + px] - dsum);
+            Dl[(t * NH + hh) * PT + px] = gs;
+            gssum += gs;
+            if (act) p.GS[o] = gs;
+            float r = gs * actf;       // d s0[b,t,h]: sum over the pixels of the tile
+#pragma unroll
+            for (int w = 1; w < PT; w <<= 1) r += __shfl_xor(r, w, 64);
+            if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + hh] = r;
+        }
+        SUMl[hh * PT + px] = asum;
+        SUMl[(NH + hh) * PT + px] = gssum;
+#pragma unroll
+        for (int j = 0; j < DV; ++j) {
+            float r = ge[j] * asum * actf;
+#pragma unroll
+            for (int w = 1; w < PT; w <<= 1) r += __shfl_xor(r, w, 64);
+            if (px == 0) p.part_bc[(size_t)blockIdx.x * NH * DV + hh * DV + j] = r;
+        }
     }
-    // V[b,h,c,pix] = sum_t gs xhat ; Z[b,h,c,pix] = sum_t attn xhat
-    float gssum = 0.f;
-    for (int t = 0; t < T; ++t) gssum += Dl[(t * 16 + hh) * 16 + px];
-    for (int c = 0; c < C; ++c) {
-        float v = 0.f, z = 0.f;
-#pragma unroll 4
+    __syncthreads();
+
+    // C: V[b,h,c,pix] = sum_t gs xhat ; Z[b,h,c,pix] = sum_t attn xhat ; channel = slot, slot + S, ...
+    for (int c = slot; c < C; c += S) {
+        float v[NH], z[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { v[h] = 0.f; z[h] = 0.f; }
         for (int t = 0; t < T; ++t) {
             const float xv = xb[(size_t)(t * C + c) * HW];
-            v += Dl[(t * 16 + hh) * 16 + px] * xv;
-            z += Al[(t * 16 + hh) * 16 + px] * xv;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                v[h] = fmaf(Dl[(t * NH + h) * PT + px], xv, v[h]);
+                z[h] = fmaf(Al[(t * NH + h) * PT + px], xv, z[h]);
+            }
         }
-        const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
-        const size_t o = (((size_t)b * NH + hh) * C + c) * HW + pix;
         if (act) {
-            p.V[o] = a * v + bb * gssum;
-            p.Z[o] = a * z + bb * asum;
+            const float a = ABl[(c * PT + px) * 2], bb = ABl[(c * PT + px) * 2 + 1];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const size_t o = (((size_t)b * NH + h) * C + c) * HW + pix;
+                p.V[o] = a * v[h] + bb * SUMl[(NH + h) * PT + px];
+                p.Z[o] = a * z[h] + bb * SUMl[h * PT + px];
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ backward, part 2
-// thread = (pixel, group): d xhat = sum_h (attn r_h + gs U_h), then per-pixel GroupNorm backward.
+// d xhat[t,c] = sum_h (attn[h,t] r[h,c] + gs[h,t] U[h,c]), then the per-pixel GroupNorm backward.
+// slot = channel slice in the two main passes, = group in the statistics step.
+template <int PT>
 __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
+    constexpr int S = 256 / PT;
     extern __shared__ float lds[];
     const int C = p.C, T = p.T, HW = p.HW;
-    float* Ul = lds;                // [16][C]
-    float* GEl = Ul + NH * C;       // [256][16]
-    float* Gl = GEl + 256 * 16;     // [T][16][16] gs
-    float* Al = Gl + T * 256;       // [T][16][16] attn
-    const int tid = threadIdx.x, px = tid & 15, g = tid >> 4;
-    const int tiles_per_b = (HW + 15) / 16;
-    const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * 16;
+    float* GEl = lds;                            // [256][PT]
+    float* Gl = GEl + 256 * PT;                  // [T][16][PT] gs
+    float* Al = Gl + T * NH * PT;                // [T][16][PT] attn
+    float* Ml = Al + T * NH * PT;                // [C][PT][2]  per-channel partial (sum dxn, sum dxn*xn)
+    float* STl = Ml + C * PT * 2;                // [16][PT][4] mean, rstd, m1, m2 of each group
+    const int tid = threadIdx.x, px = tid % PT, slot = tid / PT;
+    const int tiles_per_b = (HW + PT - 1) / PT;
+    const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * PT;
     const bool act = pix0 + px < HW;
     const float actf = act ? 1.f : 0.f;
     const int pix = act ? pix0 + px : HW - 1;
     const long pidx = (long)b * HW + pix;
     const int cpg = C / NH;
-    for (int i = tid; i < NH * C; i += 256) Ul[i] = p.U[i];
-    for (int i = tid; i < 256 * 16; i += 256) {
-        const int ch = i >> 4, q = i & 15;
-        const int pq = pix0 + q < HW ? pix0 + q : HW - 1;
-        GEl[i] = p.g_emb != nullptr ? p.g_emb[((size_t)b * 256 + ch) * HW + pq] : 0.f;
+    for (int ch = slot; ch < NH * DV; ch += S)
+        GEl[ch * PT + px] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + ch) * HW + pix] : 0.f;
+    for (int i = slot; i < T * NH; i += S) {
+        const int t = i / NH, h = i % NH;
+        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
+        Gl[i * PT + px] = p.GS[o];
+        Al[i * PT + px] = p.attn_in[o];
     }
-    for (int i = tid; i < T * 256; i += 256) {
-        const int q = i & 15, h = (i >> 4) & 15, t = i >> 8;
-        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + (pix0 + q < HW ? pix0 + q : HW - 1);
-        Gl[i] = p.GS[o];
-        Al[i] = p.attn_in[o];
+    for (int g = slot; g < NH; g += S) {
+        STl[(g * PT + px) * 4] = p.stats_in[(pidx * NH + g) * 2];
+        STl[(g * PT + px) * 4 + 1] = p.stats_in[(pidx * NH + g) * 2 + 1];
     }
     __syncthreads();
-    const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
     const float* xb = p.x + (size_t)b * T * C * HW + pix;
     float* gxb = p.gx + (size_t)b * T * C * HW + pix;
-    float m1 = 0.f, m2 = 0.f;
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = g * cpg + cc;
-        float r[NH];
+    for (int c = slot; c < C; c += S) {
+        const int g = c / cpg;
+        const float mean = STl[(g * PT + px) * 4], rstd = STl[(g * PT + px) * 4 + 1];
+        float r[NH], u[NH];
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < DV; ++j) s += GEl[(h * DV + j) * 16 + px] * p.Wc[(size_t)(h * DV + j) * C + c];
+            for (int j = 0; j < DV; ++j) s = fmaf(GEl[(h * DV + j) * PT + px], p.Wc[(size_t)(h * DV + j) * C + c], s);
             r[h] = s;
+            u[h] = p.U[h * C + c];
         }
-        float u[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) u[h] = Ul[h * C + c];
         const float gm = p.gamma[c];
-        float dg = 0.f, db = 0.f;
+        float dg = 0.f, db = 0.f, m1 = 0.f, m2 = 0.f;
         for (int t = 0; t < T; ++t) {
             float gxh = 0.f;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) gxh += Al[(t * 16 + h) * 16 + px] * r[h] + Gl[(t * 16 + h) * 16 + px] * u[h];
+            for (int h = 0; h < NH; ++h)
+                gxh = fmaf(Al[(t * NH + h) * PT + px], r[h], fmaf(Gl[(t * NH + h) * PT + px], u[h], gxh));
             const float xn = (xb[(size_t)(t * C + c) * HW] - mean) * rstd;
-            dg += gxh * xn;
+            dg = fmaf(gxh, xn, dg);
             db += gxh;
             const float dxn = gxh * gm;
             m1 += dxn;
-            m2 += dxn * xn;
+            m2 = fmaf(dxn, xn, m2);
             if (act) gxb[(size_t)(t * C + c) * HW] = dxn;
         }
+        Ml[(c * PT + px) * 2] = m1;
+        Ml[(c * PT + px) * 2 + 1] = m2;
         dg *= actf;
         db *= actf;
-        dg += __shfl_xor(dg, 1, 64); dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 4, 64); dg += __shfl_xor(dg, 8, 64);
-        db += __shfl_xor(db, 1, 64); db += __shfl_xor(db, 2, 64); db += __shfl_xor(db, 4, 64); db += __shfl_xor(db, 8, 64);
+#pragma unroll
+        for (int w = 1; w < PT; w <<= 1) { dg += __shfl_xor(dg, w, 64); db += __shfl_xor(db, w, 64); }
         if (px == 0) {
             p.part_gb[((size_t)blockIdx.x * C + c) * 2] = dg;
             p.part_gb[((size_t)blockIdx.x * C + c) * 2 + 1] = db;
         }
     }
-    const float inv_n = 1.f / (float)(cpg * T);
-    m1 *= inv_n;
-    m2 *= inv_n;
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = g * cpg + cc;
-        for (int t = 0; t < T; ++t) {
-            const size_t o = (size_t)(t * C + c) * HW;
-            const float xn = (xb[o] - mean) * rstd;
-            if (act) gxb[o] = rstd * (gxb[o] - m1 - xn * m2);
+    __syncthreads();
+    for (int g = slot; g < NH; g += S) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int cc = 0; cc < cpg; ++cc) {
+            m1 += Ml[((g * cpg + cc) * PT + px) * 2];
+            m2 += Ml[((g * cpg + cc) * PT + px) * 2 + 1];
+        }
+        const float inv_n = 1.f / (float)(cpg * T);
+        STl[(g * PT + px) * 4 + 2] = m1 * inv_n;
+        STl[(g * PT + px) * 4 + 3] = m2 * inv_n;
+    }
+    __syncthreads();
+    if (act) {
+        for (int c = slot; c < C; c += S) {
+            const int g = c / cpg;
+            const float mean = STl[(g * PT + px) * 4], rstd = STl[(g * PT + px) * 4 + 1];
+            const float m1 = STl[(g * PT + px) * 4 + 2], m2 = STl[(g * PT + px) * 4 + 3];
+            for (int t = 0; t < T; ++t) {
+                const size_t o = (size_t)(t * C + c) * HW;
+                const float xn = (xb[o] - mean) * rstd;
+                gxb[o] = rstd * (gxb[o] - m1 - xn * m2);
+            }
         }
     }
 }
@@ -516,14 +583,22 @@ size_t fwd_lds(const c2s_ltae_desc* d) {
     const size_t CH = d->C > 64 ? d->C / 2 : d->C;
     return ((size_t)d->C * 32 + (size_t)d->T * 256 + 256 + NH * CH * 16) * 4;
 }
-size_t bwd1_lds(const c2s_ltae_desc* d) { return ((size_t)d->C * 32 + (size_t)d->T * 512) * 4; }
-size_t bwd2_lds(const c2s_ltae_desc* d) { return ((size_t)NH * d->C + 256 * 16 + (size_t)d->T * 512) * 4; }
+int bwd_pt(const c2s_ltae_desc* d) { return d->T <= 32 ? 16 : 8; }
+size_t bwd1_lds(const c2s_ltae_desc* d) {
+    const size_t PT = bwd_pt(d);
+    return ((size_t)d->C * PT * 2 + 256 * PT + NH * 32 * PT + 2 * (size_t)d->T * NH * PT + 2 * NH * PT) * 4;
+}
+size_t bwd2_lds(const c2s_ltae_desc* d) {
+    const size_t PT = bwd_pt(d);
+    return (256 * PT + 2 * (size_t)d->T * NH * PT + (size_t)d->C * PT * 2 + NH * PT * 4) * 4;
+}
 
 int check(const c2s_ltae_desc* d) {
     C2S_REQUIRE(d && d->B > 0 && d->T > 0 && d->C > 0 && d->HW > 0, "ltae: bad shape");
     C2S_REQUIRE(d->n_head == NH && d->d_model == NH * DV, "ltae: only n_head=16, d_model=256 are built");
     C2S_REQUIRE(d->C % NH == 0 && d->C / NH <= 16, "ltae: C must be a multiple of 16 and <= 256");
-    C2S_REQUIRE(bwd2_lds(d) <= 160 * 1024 && fwd_lds(d) <= 160 * 1024, "ltae: T*C too large for the LDS tile");
+    C2S_REQUIRE(bwd1_lds(d) <= 160 * 1024 && bwd2_lds(d) <= 160 * 1024 && fwd_lds(d) <= 160 * 1024, "ltae: T*C too large for the LDS tile");
+    C2S_REQUIRE(d->C % 32 == 0, "ltae: C must be a multiple of 32");
     C2S_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "ltae: bad dropout p");
     return C2S_OK;
 }
@@ -561,7 +636,7 @@ extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const f
 //            | part_gb [tiles][C][2]
 extern "C" size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d) {
     if (!d) return 0;
-    const size_t tiles = (size_t)d->B * ((d->HW + 15) / 16);
+    const size_t tiles = (size_t)d->B * ((d->HW + 7) / 8);   // upper bound (8-pixel tiles)
     return (size_t)NH * d->B * d->T * d->HW + 2 * (size_t)d->B * NH * d->C * d->HW + tiles * d->T * NH + tiles * 256 +
            tiles * d->C * 2;
 }
@@ -578,7 +653,9 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
                 "ltae_bwd: null pointer");
     C2S_REQUIRE(ws_floats >= c2s_ltae_bwd_workspace_floats(d), "ltae_bwd: workspace too small");
     (void)s0; (void)valid;
-    const size_t tiles = (size_t)d->B * ((d->HW + 15) / 16);
+    const int PT = bwd_pt(d);
+    const size_t tiles = (size_t)d->B * ((d->HW + PT - 1) / PT);
+    const size_t tiles_ws = (size_t)d->B * ((d->HW + 7) / 8);
     LtaeParams p = {};
     fill(p, d);
     p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.Wc = Wc; p.bc = bc; p.pe = pe;
@@ -587,23 +664,30 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     p.V = p.GS + (size_t)NH * d->B * d->T * d->HW;
     p.Z = p.V + (size_t)d->B * NH * d->C * d->HW;
     p.part_s0 = p.Z + (size_t)d->B * NH * d->C * d->HW;
-    p.part_bc = p.part_s0 + tiles * d->T * NH;
-    p.part_gb = p.part_bc + tiles * 256;
+    p.part_bc = p.part_s0 + tiles_ws * d->T * NH;
+    p.part_gb = p.part_bc + tiles_ws * 256;
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
-    C2S_CHECK_LAUNCH("ltae_bwd_heads");
-    hipLaunchKernelGGL(ltae_bwd_gx_kernel, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
-    C2S_CHECK_LAUNCH("ltae_bwd_gx");
+    if (PT == 16) {
+        hipLaunchKernelGGL(ltae_bwd_heads_kernel<16>, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
+        C2S_CHECK_LAUNCH("ltae_bwd_heads");
+        hipLaunchKernelGGL(ltae_bwd_gx_kernel<16>, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
+        C2S_CHECK_LAUNCH("ltae_bwd_gx");
+    } else {
+        hipLaunchKernelGGL(ltae_bwd_heads_kernel<8>, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
+        C2S_CHECK_LAUNCH("ltae_bwd_heads");
+        hipLaunchKernelGGL(ltae_bwd_gx_kernel<8>, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
+        C2S_CHECK_LAUNCH("ltae_bwd_gx");
+    }
     // reductions
-    const int tpb = (d->HW + 15) / 16;
+    const int tpb = (d->HW + PT - 1) / PT;
     {   // gs0[b][t][h] = sum over the tiles of b
         const long total = (long)d->B * d->T * NH;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.part_s0, gs0, tpb,
