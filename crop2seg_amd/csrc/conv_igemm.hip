@@ -43,7 +43,7 @@ constexpr int max_plane(int K, int S) {
 
 template <int K, int S>
 struct Cfg {
-    static constexpr int CK = 8;
+    static constexpr int CK = 4;
     static constexpr int NT = K * K;
     static constexpr int MAXE = (CK * max_plane(K, S) + 255) / 256;
 };
