@@ -43,44 +43,63 @@ __device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_t
 }
 
 // ------------------------------------------------------------------------------------------ forward
-// Workgroup = 16 adjacent pixels x 16 "slots".  The slot means something different in each phase so that every
-// x element is loaded by exactly one thread per phase (no 16-fold redundant loads, 768 loads per thread in total):
-//   1 stats   : slot = GroupNorm group          (loop t, c in group)
-//   2 scores  : slot = time slice t % 16        (loop c; 16 head accumulators; U through the scalar cache)
-//   3 softmax : slot = head                     (loop t over LDS)
-//   4 z       : slot = channel slice c % 16     (loop t; 16 head accumulators) -> LDS, half of the channels at a time
-//   5 emb     : slot = head                     (loop c over LDS; Wc rows from L1/L2)
+// Workgroup = 16 adjacent pixels.  Streaming phases use threads = (pixel quad q, slot) with float4 loads (4 pixels
+// per lane; 8-16 independent 16-byte loads in flight per thread keep >= 32 KB per CU outstanding), the per-pixel
+// scalar phases use threads = (pixel, head).  Every x element is loaded by exactly one thread per phase:
+//   1 stats   : slot = (group, t mod 4)         partial sums -> LDS -> per-(pixel,group) mean / rstd
+//   2 scores  : slot = time step(s)             loop c; 16 head accumulators x 4 pixels; U through the scalar cache
+//   3 softmax : (pixel, head)                   loop t over LDS; writes attn / attn_pre
+//   4 z       : slot = channel(s)               loop t; 16 head accumulators x 4 pixels -> LDS (CH channels at a time)
+//   5 emb     : (pixel, head)                   loop c over LDS; Wc rows from L1/L2
 __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     extern __shared__ float lds[];
     const int C = p.C, T = p.T, HW = p.HW;
-    const int CH = C > 64 ? C / 2 : C;          // channels per z/emb pass
-    float* ABl = lds;                           // [C][16][2]   per-(channel,pixel) scale / shift of the GroupNorm
+    const int CH = C > 64 ? 64 : C;             // channels per z/emb pass
+    float* ABl = lds;                           // [C][2][16]   per-(channel,pixel) scale, shift of the GroupNorm
     float* Sl = ABl + C * 32;                   // [T][16][16]  scores -> attention (post-dropout)
     float* ASl = Sl + T * 256;                  // [16][16]     sum_t attention
-    float* Zl = ASl + 256;                      // [16][CH][16] z = sum_t attn * xhat
-    const int tid = threadIdx.x, px = tid & 15, slot = tid >> 4;
+    float* Zl = ASl + 256;                      // [16][CH][16] z = sum_t attn * xhat   (also the stats scratch)
+    const int tid = threadIdx.x;
+    const int q = tid & 3, slot = tid >> 2;      // streaming mapping
+    const int px = tid & 15, hh = tid >> 4;      // per-pixel mapping
     const int tiles_per_b = (HW + 15) / 16;
     const int b = blockIdx.x / tiles_per_b;
-    const int pix_raw = (blockIdx.x % tiles_per_b) * 16 + px;
-    const bool act = pix_raw < HW;                       // partial last tile: idle lanes shadow the last pixel
-    const int pix = act ? pix_raw : HW - 1;
+    const int pix0 = (blockIdx.x % tiles_per_b) * 16;
+    const bool actq = pix0 + 4 * q < HW;                 // HW % 4 == 0: a quad is entirely inside or outside
+    const int pixq = actq ? pix0 + 4 * q : 0;
+    const bool act = pix0 + px < HW;
+    const int pix = act ? pix0 + px : HW - 1;
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
-    const float* xb = p.x + (size_t)b * T * C * HW + pix;
+    const float* xq = p.x + (size_t)b * T * C * HW + pixq;     // + (t*C + c)*HW : float4 of 4 pixels
 
-    // ---- phase 1: GroupNorm statistics of group `slot` (padded frames included, tae.py:461); one pass, shifted
+    // ---- phase 1: GroupNorm statistics (padded frames included, tae.py:461); shifted sums, 4 partials per group
     {
-        const int g = slot;
-        const float K0 = xb[(size_t)(g * cpg) * HW];
-        float s = 0.f, ss = 0.f;
-        for (int t = 0; t < T; ++t) {
+        const int g = slot & 15, tq = slot >> 4;
+        const f32x4 K0 = *reinterpret_cast<const f32x4*>(xq + (size_t)(g * cpg) * HW);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+        for (int t = tq; t < T; t += 4) {
 #pragma unroll 8
             for (int cc = 0; cc < cpg; ++cc) {
-                const float d = xb[(size_t)(t * C + g * cpg + cc) * HW] - K0;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(xq + (size_t)(t * C + g * cpg + cc) * HW) - K0;
                 s += d;
                 ss += d * d;
             }
         }
+        // scratch [g][tq][2][16]
+        *reinterpret_cast<f32x4*>(Zl + ((g * 4 + tq) * 2 + 0) * 16 + 4 * q) = s;
+        *reinterpret_cast<f32x4*>(Zl + ((g * 4 + tq) * 2 + 1) * 16 + 4 * q) = ss;
+    }
+    __syncthreads();
+    {
+        const int g = hh;       // (pixel, group)
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            s += Zl[((g * 4 + tq) * 2 + 0) * 16 + px];
+            ss += Zl[((g * 4 + tq) * 2 + 1) * 16 + px];
+        }
+        const float K0 = p.x[(size_t)b * T * C * HW + (size_t)(g * cpg) * HW + pix];
         const float inv_n = 1.f / (float)(cpg * T);
         const float md = s * inv_n;
         const float mean = K0 + md;
@@ -93,33 +112,38 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
         for (int cc = 0; cc < cpg; ++cc) {
             const int c = g * cpg + cc;
             const float a = p.gamma[c] * rstd;
-            ABl[(c * 16 + px) * 2] = a;
-            ABl[(c * 16 + px) * 2 + 1] = p.beta[c] - mean * a;
+            ABl[(c * 2 + 0) * 16 + px] = a;
+            ABl[(c * 2 + 1) * 16 + px] = p.beta[c] - mean * a;
         }
     }
     __syncthreads();
 
     // ---- phase 2: scores.  U[h][c] is wave-uniform: it comes through the scalar cache, not LDS.
-    for (int t = slot; t < T; t += 16) {
-        float sc[NH];
+    for (int t = slot; t < T; t += 64) {
+        f32x4 sc[NH];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) sc[h] = p.s0[(b * T + t) * NH + h];
-        const float* xt = xb + (size_t)t * C * HW;
-#pragma unroll 4
+        for (int h = 0; h < NH; ++h) {
+            const float v = p.s0[(b * T + t) * NH + h];
+            sc[h] = (f32x4){v, v, v, v};
+        }
+        const float* xt = xq + (size_t)t * C * HW;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) {
-            const float xh = ABl[(c * 16 + px) * 2] * xt[(size_t)c * HW] + ABl[(c * 16 + px) * 2 + 1];
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + (size_t)c * HW);
+            const f32x4 xh = *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 0) * 16 + 4 * q) * xv +
+                             *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 1) * 16 + 4 * q);
 #pragma unroll
-            for (int h = 0; h < NH; ++h) sc[h] = fmaf(p.U[h * C + c], xh, sc[h]);
+            for (int h = 0; h < NH; ++h) sc[h] += p.U[h * C + c] * xh;
         }
         const bool padded = p.valid != nullptr && p.valid[b * T + t] == 0;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) Sl[(t * 16 + h) * 16 + px] = padded ? -1e6f : sc[h];   // tae.py:831
+        for (int h = 0; h < NH; ++h)
+            *reinterpret_cast<f32x4*>(Sl + (t * 16 + h) * 16 + 4 * q) = padded ? (f32x4){-1e6f, -1e6f, -1e6f, -1e6f} : sc[h];   // tae.py:831
     }
     __syncthreads();
 
-    // ---- phase 3: softmax over T for head `slot`, dropout
+    // ---- phase 3: softmax over T for (pixel, head), dropout
     {
-        const int hh = slot;
         float mx = -3.0e38f;
         for (int t = 0; t < T; ++t) mx = fmaxf(mx, Sl[(t * 16 + hh) * 16 + px]);
         float den = 0.f;
@@ -151,35 +175,34 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
 #pragma unroll
     for (int j = 0; j < DV; ++j) o[j] = 0.f;
     for (int c0 = 0; c0 < C; c0 += CH) {
-        // 4: z[h] = sum_t attn[h,t] * x[t,c] for the channels c = c0 + slot, c0 + slot + 16, ...
-        for (int c = c0 + slot; c < c0 + CH; c += 16) {
-            float z[NH];
+        // 4: z[h] = sum_t attn[h,t] * x[t,c] for channel c = c0 + slot (4 pixels per thread)
+        for (int c = c0 + slot; c < c0 + CH; c += 64) {
+            f32x4 z[NH];
 #pragma unroll
-            for (int h = 0; h < NH; ++h) z[h] = 0.f;
-#pragma unroll 2
+            for (int h = 0; h < NH; ++h) z[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int t = 0; t < T; ++t) {
-                const float xv = xb[(size_t)(t * C + c) * HW];
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xq + (size_t)(t * C + c) * HW);
 #pragma unroll
-                for (int h = 0; h < NH; ++h) z[h] = fmaf(Sl[(t * 16 + h) * 16 + px], xv, z[h]);
+                for (int h = 0; h < NH; ++h) z[h] += *reinterpret_cast<const f32x4*>(Sl + (t * 16 + h) * 16 + 4 * q) * xv;
             }
-            const float a = ABl[(c * 16 + px) * 2], bb = ABl[(c * 16 + px) * 2 + 1];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 0) * 16 + 4 * q);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 1) * 16 + 4 * q);
 #pragma unroll
-            for (int h = 0; h < NH; ++h) Zl[(h * CH + (c - c0)) * 16 + px] = a * z[h] + bb * ASl[h * 16 + px];
+            for (int h = 0; h < NH; ++h)
+                *reinterpret_cast<f32x4*>(Zl + (h * CH + (c - c0)) * 16 + 4 * q) =
+                    a * z[h] + bb * *reinterpret_cast<const f32x4*>(ASl + h * 16 + 4 * q);
         }
         __syncthreads();
-        // 5: emb slice of head `slot`
-        {
-            const int hh = slot;
-            for (int c = 0; c < CH; ++c) {
-                const float zz = Zl[(hh * CH + c) * 16 + px];
+        // 5: emb slice of (pixel, head)
+        for (int c = 0; c < CH; ++c) {
+            const float zz = Zl[(hh * CH + c) * 16 + px];
 #pragma unroll
-                for (int j = 0; j < DV; ++j) o[j] = fmaf(p.Wc[(size_t)(hh * DV + j) * C + c0 + c], zz, o[j]);
-            }
+            for (int j = 0; j < DV; ++j) o[j] = fmaf(p.Wc[(size_t)(hh * DV + j) * C + c0 + c], zz, o[j]);
         }
         __syncthreads();
     }
     {
-        const int hh = slot;
         const float asum = ASl[hh * 16 + px];
 #pragma unroll
         for (int j = 0; j < DV; ++j) o[j] += asum * p.bc[hh * DV + j];
@@ -446,16 +469,18 @@ __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ reductions
-// out[grp][k] = sum_{i<count} part[(grp*count + i)*K + k]
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int count, int K,
-                                       long total) {
-    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+// out[grp][k] = sum_{i<count} part[(grp*count + i)*K + k]; one wave per output element, lanes stride the tiles
+// (fixed lane assignment + fixed shuffle tree: bitwise reproducible)
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int count,
+                                                             int K, long total) {
+    const long e = blockIdx.x;
     if (e >= total) return;
     const long grp = e / K;
     const int k = (int)(e % K);
     double s = 0.0;
-    for (int i = 0; i < count; ++i) s += part[((size_t)grp * count + i) * K + k];
-    out[e] = (float)s;
+    for (int i = threadIdx.x; i < count; i += 64) s += part[((size_t)grp * count + i) * K + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[e] = (float)s;
 }
 
 // gU[h,c] = sum_{b,pix} V[b,h,c,pix]     one wave per (h,c)
@@ -580,7 +605,7 @@ __global__ void dropout_nchw_kernel(const float* __restrict__ x, float* __restri
 }
 
 size_t fwd_lds(const c2s_ltae_desc* d) {
-    const size_t CH = d->C > 64 ? d->C / 2 : d->C;
+    const size_t CH = d->C > 64 ? 64 : d->C;
     return ((size_t)d->C * 32 + (size_t)d->T * 256 + 256 + NH * CH * 16) * 4;
 }
 int bwd_pt(const c2s_ltae_desc* d) { return d->T <= 32 ? 16 : 8; }
@@ -598,7 +623,8 @@ int check(const c2s_ltae_desc* d) {
     C2S_REQUIRE(d->n_head == NH && d->d_model == NH * DV, "ltae: only n_head=16, d_model=256 are built");
     C2S_REQUIRE(d->C % NH == 0 && d->C / NH <= 16, "ltae: C must be a multiple of 16 and <= 256");
     C2S_REQUIRE(bwd1_lds(d) <= 160 * 1024 && bwd2_lds(d) <= 160 * 1024 && fwd_lds(d) <= 160 * 1024, "ltae: T*C too large for the LDS tile");
-    C2S_REQUIRE(d->C % 32 == 0, "ltae: C must be a multiple of 32");
+    C2S_REQUIRE(d->C % 64 == 0, "ltae: C must be a multiple of 64");
+    C2S_REQUIRE(d->HW % 4 == 0, "ltae: h*w must be a multiple of 4");
     C2S_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "ltae: bad dropout p");
     return C2S_OK;
 }
@@ -690,15 +716,15 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     const int tpb = (d->HW + PT - 1) / PT;
     {   // gs0[b][t][h] = sum over the tiles of b
         const long total = (long)d->B * d->T * NH;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.part_s0, gs0, tpb,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(total), dim3(64), 0, st, p.part_s0, gs0, tpb,
                            d->T * NH, total);
         C2S_CHECK_LAUNCH("ltae_reduce_s0");
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.part_bc, gbc, (int)tiles, 256, (long)256);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(256), dim3(64), 0, st, p.part_bc, gbc, (int)tiles, 256, (long)256);
     C2S_CHECK_LAUNCH("ltae_reduce_bc");
     {   // interleaved (dgamma, dbeta) -> two outputs: reduce into a [C][2] scratch then split (reuse part_bc tail)
         float* gb = p.part_bc;   // part_bc is consumed above; 2*C <= 256 floats fit in its first entries
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * d->C, 256)), dim3(256), 0, st, p.part_gb, gb, (int)tiles,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * d->C), dim3(64), 0, st, p.part_gb, gb, (int)tiles,
                            2 * d->C, (long)2 * d->C);
         C2S_CHECK_LAUNCH("ltae_reduce_gb");
         hipMemcpy2DAsync(ggamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
@@ -742,7 +768,7 @@ extern "C" int c2s_pixel_gn_bwd(const float* x, const float* gy, const float* ga
                        B, C, HW, groups, chunks);
     C2S_CHECK_LAUNCH("pixel_gn_bwd");
     float* gb = workspace + (size_t)B * chunks * C * 2;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, workspace, gb, B * chunks, 2 * C,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * C), dim3(64), 0, st, workspace, gb, B * chunks, 2 * C,
                        (long)2 * C);
     C2S_CHECK_LAUNCH("pixel_gn_reduce");
     hipMemcpy2DAsync(dgamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), C, hipMemcpyDeviceToDevice, st);
