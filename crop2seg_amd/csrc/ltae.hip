@@ -220,46 +220,52 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
 
 // ------------------------------------------------------------------------------------------ backward, part 1
 // Softmax/dropout backward -> GS (d score), V = sum_t gs xhat, Z = sum_t attn xhat, per-tile partials of d s0 and
-// d bc.  Workgroup = PT adjacent pixels x S = 256/PT slots (PT = 16 for T <= 32, 8 for longer series so that the
-// [T][16][PT] tiles fit in LDS); like the forward kernel the slot changes meaning per phase:
-//   A1 r[h][c] = sum_j ge[16h+j] Wc[16h+j][c]   slot -> (h, c) items          (RC channels at a time)
-//   A2 dot[h,t] += r[h][c] xhat[t,c]            slot = time slice
-//   B  softmax / dropout backward               slot = head
-//   C  V, Z                                     slot = channel slice
-template <int PT>
+// d bc.  Workgroup = 8 adjacent pixels (so that the [T][16][8] tiles fit in LDS up to T = 64).  Streaming phases use
+// threads = (pixel quad q in {0,1}, slot in [0,128)) with float4 loads, per-pixel phases use (pixel, item):
+//   A1 r[h][c] = sum_j ge[16h+j] Wc[16h+j][c]   (pixel, 32 items)      RC channels at a time
+//   A2 dot[h,t] += r[h][c] xhat[t,c]            slot = (t, channel half of the chunk); halves add in turn
+//   B  softmax / dropout backward               (pixel, head)
+//   C  V (slots 0..63) and Z (slots 64..127)     slot % 64 = channel
+constexpr int BPT = 8;      // pixels per backward tile
+
 __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
-    constexpr int S = 256 / PT;
+    constexpr int PT = BPT;
     constexpr int RC = 32;                       // channels per r-chunk
     extern __shared__ float lds[];
     const int C = p.C, T = p.T, HW = p.HW;
-    float* ABl = lds;                            // [C][PT][2]
-    float* GEl = ABl + C * PT * 2;               // [256][PT]
+    float* ABl = lds;                            // [C][2][PT]
+    float* GEl = ABl + C * 2 * PT;               // [256][PT]
     float* Rl = GEl + 256 * PT;                  // [16][RC][PT]
     float* Dl = Rl + NH * RC * PT;               // [T][16][PT]  dot -> ga -> gs
     float* Al = Dl + T * NH * PT;                // [T][16][PT]  attention (post-dropout)
     float* SUMl = Al + T * NH * PT;              // [2][16][PT]  sum_t attn, sum_t gs
-    const int tid = threadIdx.x, px = tid % PT, slot = tid / PT;
+    const int tid = threadIdx.x;
+    const int px = tid & 7, item = tid >> 3;     // per-pixel mapping: 8 pixels x 32 items
+    const int q = tid & 1, slot = tid >> 1;      // streaming mapping: 2 quads x 128 slots
     const int tiles_per_b = (HW + PT - 1) / PT;
     const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * PT;
     const bool act = pix0 + px < HW;
     const float actf = act ? 1.f : 0.f;
     const int pix = act ? pix0 + px : HW - 1;
+    const bool actq = pix0 + 4 * q < HW;
+    const int pixq = actq ? pix0 + 4 * q : 0;
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
-    const float* xb = p.x + (size_t)b * T * C * HW + pix;
+    const float* xq = p.x + (size_t)b * T * C * HW + pixq;
 
-    for (int g = slot; g < NH; g += S) {
+    if (item < NH) {
+        const int g = item;
         const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
         for (int cc = 0; cc < cpg; ++cc) {
             const int c = g * cpg + cc;
             const float a = p.gamma[c] * rstd;
-            ABl[(c * PT + px) * 2] = a;
-            ABl[(c * PT + px) * 2 + 1] = p.beta[c] - mean * a;
+            ABl[(c * 2 + 0) * PT + px] = a;
+            ABl[(c * 2 + 1) * PT + px] = p.beta[c] - mean * a;
         }
     }
-    for (int ch = slot; ch < NH * DV; ch += S)
+    for (int ch = item; ch < NH * DV; ch += 32)
         GEl[ch * PT + px] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + ch) * HW + pix] : 0.f;
-    for (int i = slot; i < T * NH; i += S) {
+    for (int i = item; i < T * NH; i += 32) {
         const int t = i / NH, h = i % NH;
         Dl[i * PT + px] = 0.f;
         Al[i * PT + px] = p.attn_in[((size_t)(h * p.B + b) * T + t) * HW + pix];
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
     if (p.g_emb != nullptr) {
         for (int c0 = 0; c0 < C; c0 += RC) {
             // A1
-            for (int it = slot; it < NH * RC; it += S) {
+            for (int it = item; it < NH * RC; it += 32) {
                 const int h = it / RC, cc = it % RC;
                 float r = 0.f;
 #pragma unroll
@@ -277,29 +283,40 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
                 Rl[it * PT + px] = r;
             }
             __syncthreads();
-            // A2
-            for (int t = slot; t < T; t += S) {
-                float acc[NH];
+            // A2: slot = (t, half); each half covers RC/2 channels of the chunk
+            const int t = slot >> 1, half = slot & 1;
+            f32x4 acc[NH];
 #pragma unroll
-                for (int h = 0; h < NH; ++h) acc[h] = 0.f;
-                const float* xt = xb + (size_t)t * C * HW;
-#pragma unroll 2
-                for (int cc = 0; cc < RC; ++cc) {
+            for (int h = 0; h < NH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t < T) {
+                const float* xt = xq + (size_t)t * C * HW;
+#pragma unroll 4
+                for (int cc = half * (RC / 2); cc < (half + 1) * (RC / 2); ++cc) {
                     const int c = c0 + cc;
-                    const float xh = ABl[(c * PT + px) * 2] * xt[(size_t)c * HW] + ABl[(c * PT + px) * 2 + 1];
+                    const f32x4 xh = *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 0) * PT + 4 * q) *
+                                         *reinterpret_cast<const f32x4*>(xt + (size_t)c * HW) +
+                                     *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 1) * PT + 4 * q);
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) acc[h] = fmaf(Rl[(h * RC + cc) * PT + px], xh, acc[h]);
+                    for (int h = 0; h < NH; ++h) acc[h] += *reinterpret_cast<const f32x4*>(Rl + (h * RC + cc) * PT + 4 * q) * xh;
                 }
-#pragma unroll
-                for (int h = 0; h < NH; ++h) Dl[(t * NH + h) * PT + px] += acc[h];
             }
-            __syncthreads();
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (t < T && half == hf) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        f32x4* d = reinterpret_cast<f32x4*>(Dl + (t * NH + h) * PT + 4 * q);
+                        *d = *d + acc[h];
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 
-    // B: head = slot
-    if (slot < NH) {
-        const int hh = slot;
+    // B: (pixel, head)
+    if (item < NH) {
+        const int hh = item;
         float ge[DV];
         float gebc = 0.f;
 #pragma unroll
@@ -327,8 +344,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
             gssum += gs;
             if (act) p.GS[o] = gs;
             float r = gs * actf;       // d s0[b,t,h]: sum over the pixels of the tile
-#pragma unroll
-            for (int w = 1; w < PT; w <<= 1) r += __shfl_xor(r, w, 64);
+            r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
             if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + hh] = r;
         }
         SUMl[hh * PT + px] = asum;
@@ -336,33 +352,36 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
 #pragma unroll
         for (int j = 0; j < DV; ++j) {
             float r = ge[j] * asum * actf;
-#pragma unroll
-            for (int w = 1; w < PT; w <<= 1) r += __shfl_xor(r, w, 64);
+            r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
             if (px == 0) p.part_bc[(size_t)blockIdx.x * NH * DV + hh * DV + j] = r;
         }
     }
     __syncthreads();
 
-    // C: V[b,h,c,pix] = sum_t gs xhat ; Z[b,h,c,pix] = sum_t attn xhat ; channel = slot, slot + S, ...
-    for (int c = slot; c < C; c += S) {
-        float v[NH], z[NH];
+    // C: slots 0..63 produce V = sum_t gs xhat, slots 64..127 produce Z = sum_t attn xhat; channel = slot % 64 (+64)
+    {
+        const bool isz = slot >= 64;
+        const float* Wl_ = isz ? Al : Dl;
+        float* outp = isz ? p.Z : p.V;
+        const float* suml = isz ? SUMl : SUMl + NH * PT;
+        for (int c = slot & 63; c < C; c += 64) {
+            f32x4 v[NH];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) { v[h] = 0.f; z[h] = 0.f; }
-        for (int t = 0; t < T; ++t) {
-            const float xv = xb[(size_t)(t * C + c) * HW];
+            for (int h = 0; h < NH; ++h) v[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int t = 0; t < T; ++t) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xq + (size_t)(t * C + c) * HW);
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                v[h] = fmaf(Dl[(t * NH + h) * PT + px], xv, v[h]);
-                z[h] = fmaf(Al[(t * NH + h) * PT + px], xv, z[h]);
+                for (int h = 0; h < NH; ++h) v[h] += *reinterpret_cast<const f32x4*>(Wl_ + (t * NH + h) * PT + 4 * q) * xv;
             }
-        }
-        if (act) {
-            const float a = ABl[(c * PT + px) * 2], bb = ABl[(c * PT + px) * 2 + 1];
+            if (actq) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 0) * PT + 4 * q);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(ABl + (c * 2 + 1) * PT + 4 * q);
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                const size_t o = (((size_t)b * NH + h) * C + c) * HW + pix;
-                p.V[o] = a * v[h] + bb * SUMl[(NH + h) * PT + px];
-                p.Z[o] = a * z[h] + bb * SUMl[h * PT + px];
+                for (int h = 0; h < NH; ++h) {
+                    const size_t o = (((size_t)b * NH + h) * C + c) * HW + pixq;
+                    *reinterpret_cast<f32x4*>(outp + o) = a * v[h] + bb * *reinterpret_cast<const f32x4*>(suml + h * PT + 4 * q);
+                }
             }
         }
     }
@@ -370,99 +389,115 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
 
 // ------------------------------------------------------------------------------------------ backward, part 2
 // d xhat[t,c] = sum_h (attn[h,t] r[h,c] + gs[h,t] U[h,c]), then the per-pixel GroupNorm backward.
-// slot = channel slice in the two main passes, = group in the statistics step.
-template <int PT>
+// Streaming threads = (quad, slot): slot = (channel c = slot % 64 (+64), time half th = slot / 64).
 __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
-    constexpr int S = 256 / PT;
+    constexpr int PT = BPT;
     extern __shared__ float lds[];
     const int C = p.C, T = p.T, HW = p.HW;
     float* GEl = lds;                            // [256][PT]
     float* Gl = GEl + 256 * PT;                  // [T][16][PT] gs
     float* Al = Gl + T * NH * PT;                // [T][16][PT] attn
-    float* Ml = Al + T * NH * PT;                // [C][PT][2]  per-channel partial (sum dxn, sum dxn*xn)
-    float* STl = Ml + C * PT * 2;                // [16][PT][4] mean, rstd, m1, m2 of each group
-    const int tid = threadIdx.x, px = tid % PT, slot = tid / PT;
+    float* Ml = Al + T * NH * PT;                // [C][2 th][2][PT]  partial (sum dxn, sum dxn*xn)
+    float* STl = Ml + C * 4 * PT;                // [16][4][PT] mean, rstd, m1, m2 of each group
+    float* Pl = STl + NH * 4 * PT;               // [C][2 th][2 q][2]  partial (dgamma, dbeta)
+    const int tid = threadIdx.x;
+    const int px = tid & 7, item = tid >> 3;
+    const int q = tid & 1, slot = tid >> 1;
     const int tiles_per_b = (HW + PT - 1) / PT;
     const int b = blockIdx.x / tiles_per_b, pix0 = (blockIdx.x % tiles_per_b) * PT;
     const bool act = pix0 + px < HW;
-    const float actf = act ? 1.f : 0.f;
     const int pix = act ? pix0 + px : HW - 1;
+    const bool actq = pix0 + 4 * q < HW;
+    const float actqf = actq ? 1.f : 0.f;
+    const int pixq = actq ? pix0 + 4 * q : 0;
     const long pidx = (long)b * HW + pix;
     const int cpg = C / NH;
-    for (int ch = slot; ch < NH * DV; ch += S)
+    for (int ch = item; ch < NH * DV; ch += 32)
         GEl[ch * PT + px] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + ch) * HW + pix] : 0.f;
-    for (int i = slot; i < T * NH; i += S) {
+    for (int i = item; i < T * NH; i += 32) {
         const int t = i / NH, h = i % NH;
         const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
         Gl[i * PT + px] = p.GS[o];
         Al[i * PT + px] = p.attn_in[o];
     }
-    for (int g = slot; g < NH; g += S) {
-        STl[(g * PT + px) * 4] = p.stats_in[(pidx * NH + g) * 2];
-        STl[(g * PT + px) * 4 + 1] = p.stats_in[(pidx * NH + g) * 2 + 1];
+    if (item < NH) {
+        STl[(item * 4 + 0) * PT + px] = p.stats_in[(pidx * NH + item) * 2];
+        STl[(item * 4 + 1) * PT + px] = p.stats_in[(pidx * NH + item) * 2 + 1];
     }
     __syncthreads();
-    const float* xb = p.x + (size_t)b * T * C * HW + pix;
-    float* gxb = p.gx + (size_t)b * T * C * HW + pix;
-    for (int c = slot; c < C; c += S) {
+    const float* xq = p.x + (size_t)b * T * C * HW + pixq;
+    float* gxq = p.gx + (size_t)b * T * C * HW + pixq;
+    const int th = slot >> 6;
+    const int t_beg = th == 0 ? 0 : (T + 1) / 2, t_end = th == 0 ? (T + 1) / 2 : T;
+    for (int c = slot & 63; c < C; c += 64) {
         const int g = c / cpg;
-        const float mean = STl[(g * PT + px) * 4], rstd = STl[(g * PT + px) * 4 + 1];
-        float r[NH], u[NH];
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(STl + (g * 4 + 0) * PT + 4 * q);
+        const f32x4 rstd = *reinterpret_cast<const f32x4*>(STl + (g * 4 + 1) * PT + 4 * q);
+        f32x4 r[NH];
+        float u[NH];
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            float s = 0.f;
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < DV; ++j) s = fmaf(GEl[(h * DV + j) * PT + px], p.Wc[(size_t)(h * DV + j) * C + c], s);
-            r[h] = s;
+            for (int j = 0; j < DV; ++j)
+                sacc += *reinterpret_cast<const f32x4*>(GEl + (h * DV + j) * PT + 4 * q) * p.Wc[(size_t)(h * DV + j) * C + c];
+            r[h] = sacc;
             u[h] = p.U[h * C + c];
         }
         const float gm = p.gamma[c];
-        float dg = 0.f, db = 0.f, m1 = 0.f, m2 = 0.f;
-        for (int t = 0; t < T; ++t) {
-            float gxh = 0.f;
+        f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = dg, m1 = dg, m2 = dg;
+        for (int t = t_beg; t < t_end; ++t) {
+            f32x4 gxh = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < NH; ++h)
-                gxh = fmaf(Al[(t * NH + h) * PT + px], r[h], fmaf(Gl[(t * NH + h) * PT + px], u[h], gxh));
-            const float xn = (xb[(size_t)(t * C + c) * HW] - mean) * rstd;
-            dg = fmaf(gxh, xn, dg);
+                gxh += *reinterpret_cast<const f32x4*>(Al + (t * NH + h) * PT + 4 * q) * r[h] +
+                       *reinterpret_cast<const f32x4*>(Gl + (t * NH + h) * PT + 4 * q) * u[h];
+            const f32x4 xn = (*reinterpret_cast<const f32x4*>(xq + (size_t)(t * C + c) * HW) - mean) * rstd;
+            dg += gxh * xn;
             db += gxh;
-            const float dxn = gxh * gm;
+            const f32x4 dxn = gxh * gm;
             m1 += dxn;
-            m2 = fmaf(dxn, xn, m2);
-            if (act) gxb[(size_t)(t * C + c) * HW] = dxn;
+            m2 += dxn * xn;
+            if (actq) *reinterpret_cast<f32x4*>(gxq + (size_t)(t * C + c) * HW) = dxn;
         }
-        Ml[(c * PT + px) * 2] = m1;
-        Ml[(c * PT + px) * 2 + 1] = m2;
-        dg *= actf;
-        db *= actf;
-#pragma unroll
-        for (int w = 1; w < PT; w <<= 1) { dg += __shfl_xor(dg, w, 64); db += __shfl_xor(db, w, 64); }
-        if (px == 0) {
-            p.part_gb[((size_t)blockIdx.x * C + c) * 2] = dg;
-            p.part_gb[((size_t)blockIdx.x * C + c) * 2 + 1] = db;
-        }
+        *reinterpret_cast<f32x4*>(Ml + ((c * 2 + th) * 2 + 0) * PT + 4 * q) = m1;
+        *reinterpret_cast<f32x4*>(Ml + ((c * 2 + th) * 2 + 1) * PT + 4 * q) = m2;
+        Pl[((c * 2 + th) * 2 + q) * 2 + 0] = ((dg.x + dg.y) + (dg.z + dg.w)) * actqf;
+        Pl[((c * 2 + th) * 2 + q) * 2 + 1] = ((db.x + db.y) + (db.z + db.w)) * actqf;
     }
     __syncthreads();
-    for (int g = slot; g < NH; g += S) {
+    if (item < NH) {
+        const int g = item;
         float m1 = 0.f, m2 = 0.f;
-        for (int cc = 0; cc < cpg; ++cc) {
-            m1 += Ml[((g * cpg + cc) * PT + px) * 2];
-            m2 += Ml[((g * cpg + cc) * PT + px) * 2 + 1];
-        }
+        for (int cc = 0; cc < cpg; ++cc)
+            for (int h2 = 0; h2 < 2; ++h2) {
+                m1 += Ml[(((g * cpg + cc) * 2 + h2) * 2 + 0) * PT + px];
+                m2 += Ml[(((g * cpg + cc) * 2 + h2) * 2 + 1) * PT + px];
+            }
         const float inv_n = 1.f / (float)(cpg * T);
-        STl[(g * PT + px) * 4 + 2] = m1 * inv_n;
-        STl[(g * PT + px) * 4 + 3] = m2 * inv_n;
+        STl[(g * 4 + 2) * PT + px] = m1 * inv_n;
+        STl[(g * 4 + 3) * PT + px] = m2 * inv_n;
+    }
+    for (int c = tid; c < C; c += 256) {
+        const float dg = (Pl[((c * 2 + 0) * 2 + 0) * 2] + Pl[((c * 2 + 0) * 2 + 1) * 2]) + (Pl[((c * 2 + 1) * 2 + 0) * 2] + Pl[((c * 2 + 1) * 2 + 1) * 2]);
+        const float db = (Pl[((c * 2 + 0) * 2 + 0) * 2 + 1] + Pl[((c * 2 + 0) * 2 + 1) * 2 + 1]) +
+                         (Pl[((c * 2 + 1) * 2 + 0) * 2 + 1] + Pl[((c * 2 + 1) * 2 + 1) * 2 + 1]);
+        p.part_gb[((size_t)blockIdx.x * C + c) * 2] = dg;
+        p.part_gb[((size_t)blockIdx.x * C + c) * 2 + 1] = db;
     }
     __syncthreads();
-    if (act) {
-        for (int c = slot; c < C; c += S) {
+    if (actq) {
+        for (int c = slot & 63; c < C; c += 64) {
             const int g = c / cpg;
-            const float mean = STl[(g * PT + px) * 4], rstd = STl[(g * PT + px) * 4 + 1];
-            const float m1 = STl[(g * PT + px) * 4 + 2], m2 = STl[(g * PT + px) * 4 + 3];
-            for (int t = 0; t < T; ++t) {
+            const f32x4 mean = *reinterpret_cast<const f32x4*>(STl + (g * 4 + 0) * PT + 4 * q);
+            const f32x4 rstd = *reinterpret_cast<const f32x4*>(STl + (g * 4 + 1) * PT + 4 * q);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(STl + (g * 4 + 2) * PT + 4 * q);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(STl + (g * 4 + 3) * PT + 4 * q);
+            for (int t = t_beg; t < t_end; ++t) {
                 const size_t o = (size_t)(t * C + c) * HW;
-                const float xn = (xb[o] - mean) * rstd;
-                gxb[o] = rstd * (gxb[o] - m1 - xn * m2);
+                const f32x4 xn = (*reinterpret_cast<const f32x4*>(xq + o) - mean) * rstd;
+                f32x4* gp = reinterpret_cast<f32x4*>(gxq + o);
+                *gp = rstd * (*gp - m1 - xn * m2);
             }
         }
     }
@@ -608,20 +643,20 @@ size_t fwd_lds(const c2s_ltae_desc* d) {
     const size_t CH = d->C > 64 ? 64 : d->C;
     return ((size_t)d->C * 32 + (size_t)d->T * 256 + 256 + NH * CH * 16) * 4;
 }
-int bwd_pt(const c2s_ltae_desc* d) { return d->T <= 32 ? 16 : 8; }
+int bwd_pt(const c2s_ltae_desc*) { return BPT; }
 size_t bwd1_lds(const c2s_ltae_desc* d) {
-    const size_t PT = bwd_pt(d);
-    return ((size_t)d->C * PT * 2 + 256 * PT + NH * 32 * PT + 2 * (size_t)d->T * NH * PT + 2 * NH * PT) * 4;
+    const size_t PT = BPT;
+    return ((size_t)d->C * 2 * PT + 256 * PT + NH * 32 * PT + 2 * (size_t)d->T * NH * PT + 2 * NH * PT) * 4;
 }
 size_t bwd2_lds(const c2s_ltae_desc* d) {
-    const size_t PT = bwd_pt(d);
-    return (256 * PT + 2 * (size_t)d->T * NH * PT + (size_t)d->C * PT * 2 + NH * PT * 4) * 4;
+    const size_t PT = BPT;
+    return (256 * PT + 2 * (size_t)d->T * NH * PT + (size_t)d->C * 4 * PT + NH * 4 * PT + (size_t)d->C * 8) * 4;
 }
 
 int check(const c2s_ltae_desc* d) {
     C2S_REQUIRE(d && d->B > 0 && d->T > 0 && d->C > 0 && d->HW > 0, "ltae: bad shape");
     C2S_REQUIRE(d->n_head == NH && d->d_model == NH * DV, "ltae: only n_head=16, d_model=256 are built");
-    C2S_REQUIRE(d->C % NH == 0 && d->C / NH <= 16, "ltae: C must be a multiple of 16 and <= 256");
+    C2S_REQUIRE(d->C % NH == 0 && d->C / NH <= 16 && d->T <= 64, "ltae: C must be a multiple of 16 and <= 256, T <= 64");
     C2S_REQUIRE(bwd1_lds(d) <= 160 * 1024 && bwd2_lds(d) <= 160 * 1024 && fwd_lds(d) <= 160 * 1024, "ltae: T*C too large for the LDS tile");
     C2S_REQUIRE(d->C % 64 == 0, "ltae: C must be a multiple of 64");
     C2S_REQUIRE(d->HW % 4 == 0, "ltae: h*w must be a multiple of 4");
@@ -695,23 +730,14 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (PT == 16) {
-        hipLaunchKernelGGL(ltae_bwd_heads_kernel<16>, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
-        C2S_CHECK_LAUNCH("ltae_bwd_heads");
-        hipLaunchKernelGGL(ltae_bwd_gx_kernel<16>, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
-        C2S_CHECK_LAUNCH("ltae_bwd_gx");
-    } else {
-        hipLaunchKernelGGL(ltae_bwd_heads_kernel<8>, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
-        C2S_CHECK_LAUNCH("ltae_bwd_heads");
-        hipLaunchKernelGGL(ltae_bwd_gx_kernel<8>, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
-        C2S_CHECK_LAUNCH("ltae_bwd_gx");
-    }
+    hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
+    C2S_CHECK_LAUNCH("ltae_bwd_heads");
+    hipLaunchKernelGGL(ltae_bwd_gx_kernel, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
+    C2S_CHECK_LAUNCH("ltae_bwd_gx");
     // reductions
     const int tpb = (d->HW + PT - 1) / PT;
     {   // gs0[b][t][h] = sum over the tiles of b
