@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
     float* Rl = GEl + 256 * PT;                  // [16][RC][PT]
     float* Dl = Rl + NH * RC * PT;               // [T][16][PT]  dot -> ga -> gs
     float* Al = Dl + T * NH * PT;                // [T][16][PT]  attention (post-dropout)
-    float* SUMl = Al + T * NH * PT;              // [2][16][PT]  sum_t attn, sum_t gs
+    float* APl = Al + T * NH * PT;               // [T][16][PT]  attention before dropout (softmax output)
+    float* GAl = APl + T * NH * PT;              // [T][16][PT]  incoming d attn
+    float* SUMl = GAl + T * NH * PT;             // [2][16][PT]  sum_t attn, sum_t gs
     const int tid = threadIdx.x;
     const int px = tid & 7, item = tid >> 3;     // per-pixel mapping: 8 pixels x 32 items
     const int q = tid & 1, slot = tid >> 1;      // streaming mapping: 2 quads x 128 slots
@@ -265,10 +267,15 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
     }
     for (int ch = item; ch < NH * DV; ch += 32)
         GEl[ch * PT + px] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + ch) * HW + pix] : 0.f;
-    for (int i = item; i < T * NH; i += 32) {
+    // tiles of attn / attn_pre / d attn: float4 (pixel quad) loads, all issued back to back
+    for (int i = slot; i < T * NH; i += 128) {
         const int t = i / NH, h = i % NH;
-        Dl[i * PT + px] = 0.f;
-        Al[i * PT + px] = p.attn_in[((size_t)(h * p.B + b) * T + t) * HW + pix];
+        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pixq;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Dl + i * PT + 4 * q) = z4;
+        *reinterpret_cast<f32x4*>(Al + i * PT + 4 * q) = *reinterpret_cast<const f32x4*>(p.attn_in + o);
+        *reinterpret_cast<f32x4*>(APl + i * PT + 4 * q) = *reinterpret_cast<const f32x4*>(p.attn_pre_in + o);
+        *reinterpret_cast<f32x4*>(GAl + i * PT + 4 * q) = p.g_attn != nullptr ? *reinterpret_cast<const f32x4*>(p.g_attn + o) : z4;
     }
     __syncthreads();
 
@@ -327,19 +334,18 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
         float dsum = 0.f, asum = 0.f;
         for (int t = 0; t < T; ++t) {
             const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
-            float gap = Dl[(t * NH + hh) * PT + px] + gebc;
-            if (p.g_attn != nullptr) gap += p.g_attn[o];
+            float gap = Dl[(t * NH + hh) * PT + px] + gebc + GAl[(t * NH + hh) * PT + px];
 #pragma unroll
             for (int j = 0; j < DV; ++j) gap = fmaf(ge[j], p.pe[(b * T + t) * DV + j], gap);
             const float ga = gap * keep_scale(p, hh, Ptot, pidx, t);
-            dsum = fmaf(p.attn_pre_in[o], ga, dsum);
+            dsum = fmaf(APl[(t * NH + hh) * PT + px], ga, dsum);
             Dl[(t * NH + hh) * PT + px] = ga;
             asum += Al[(t * NH + hh) * PT + px];
         }
         float gssum = 0.f;
         for (int t = 0; t < T; ++t) {
             const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
-            const float gs = p.attn_pre_in[o] * (Dl[(t * NH + hh) * PT + px] - dsum);
+            const float gs = APl[(t * NH + hh) * PT + px] * (Dl[(t * NH + hh) * PT + px] - dsum);
             Dl[(t * NH + hh) * PT + px] = gs;
             gssum += gs;
             if (act) p.GS[o] = gs;
@@ -414,11 +420,16 @@ __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
     const int cpg = C / NH;
     for (int ch = item; ch < NH * DV; ch += 32)
         GEl[ch * PT + px] = p.g_emb != nullptr ? p.g_emb[((size_t)b * NH * DV + ch) * HW + pix] : 0.f;
-    for (int i = item; i < T * NH; i += 32) {
-        const int t = i / NH, h = i % NH;
-        const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
-        Gl[i * PT + px] = p.GS[o];
-        Al[i * PT + px] = p.attn_in[o];
+    {
+        const int q_ = tid & 1, slot_ = tid >> 1;
+        const bool actq_ = pix0 + 4 * q_ < HW;
+        const int pixq_ = actq_ ? pix0 + 4 * q_ : 0;
+        for (int i = slot_; i < T * NH; i += 128) {
+            const int t = i / NH, h = i % NH;
+            const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pixq_;
+            *reinterpret_cast<f32x4*>(Gl + i * PT + 4 * q_) = *reinterpret_cast<const f32x4*>(p.GS + o);
+            *reinterpret_cast<f32x4*>(Al + i * PT + 4 * q_) = *reinterpret_cast<const f32x4*>(p.attn_in + o);
+        }
     }
     if (item < NH) {
         STl[(item * 4 + 0) * PT + px] = p.stats_in[(pidx * NH + item) * 2];
@@ -646,7 +657,7 @@ size_t fwd_lds(const c2s_ltae_desc* d) {
 int bwd_pt(const c2s_ltae_desc*) { return BPT; }
 size_t bwd1_lds(const c2s_ltae_desc* d) {
     const size_t PT = BPT;
-    return ((size_t)d->C * 2 * PT + 256 * PT + NH * 32 * PT + 2 * (size_t)d->T * NH * PT + 2 * NH * PT) * 4;
+    return ((size_t)d->C * 2 * PT + 256 * PT + NH * 32 * PT + 4 * (size_t)d->T * NH * PT + 2 * NH * PT) * 4;
 }
 size_t bwd2_lds(const c2s_ltae_desc* d) {
     const size_t PT = BPT;
