@@ -38,104 +38,133 @@ __global__ __launch_bounds__(256) void frame_flags_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- depthwise conv (conv.py:18-24)
-__global__ void dw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
-                              const int* __restrict__ valid, int N, int C, int Hin, int Win, int K, int S, int pad,
-                              int reflect) {
+// HBM-bound.  grid = (pixel blocks, N*C planes); (K,S) are template parameters so the tap loops unroll and the
+// K*K weights of the plane sit in registers.
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     float* __restrict__ out, const int* __restrict__ valid, int C,
+                                                     int Hin, int Win, int pad, int reflect) {
+    const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    if (valid != nullptr && valid[n] == 0) return;
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
-    const long total = (long)N * C * Ho * Wo;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(e % Wo);
-        long r = e / Wo;
-        const int oy = (int)(r % Ho); r /= Ho;
-        const int c = (int)(r % C), n = (int)(r / C);
-        if (valid != nullptr && valid[n] == 0) continue;
-        const float* ip = in + ((size_t)n * C + c) * Hin * Win;
-        const float* wp = w + (size_t)c * K * K;
-        float acc = 0.f;
-        for (int ky = 0; ky < K; ++ky) {
-            int gy = oy * S - pad + ky;
-            if (reflect) gy = reflect_idx(gy, Hin); else if (gy < 0 || gy >= Hin) continue;
-            for (int kx = 0; kx < K; ++kx) {
-                int gx = ox * S - pad + kx;
-                if (reflect) gx = reflect_idx(gx, Win); else if (gx < 0 || gx >= Win) continue;
-                acc += wp[ky * K + kx] * ip[gy * Win + gx];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Ho * Wo) return;
+    const int oy = e / Wo, ox = e - oy * Wo;
+    float wk[K * K];
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = w[(size_t)c * K * K + k];
+    const float* ip = in + (size_t)plane * Hin * Win;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        int gy = oy * S - pad + ky;
+        bool oky = true;
+        if (reflect) gy = reflect_idx(gy, Hin); else oky = gy >= 0 && gy < Hin;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            int gx = ox * S - pad + kx;
+            bool ok = oky;
+            if (reflect) gx = reflect_idx(gx, Win); else ok = ok && gx >= 0 && gx < Win;
+            const float v = ip[ok ? gy * Win + gx : 0];
+            acc = fmaf(wk[ky * K + kx], ok ? v : 0.f, acc);
+        }
+    }
+    out[(size_t)plane * Ho * Wo + e] = acc;
+}
+
+// data gradient, gather form: input pixel j receives from the padded positions that reflect onto it
+// (j itself; -1 if j == 1; n if j == n-2) through every tap whose output index is integral and in range
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w,
+                                                       float* __restrict__ gin, const int* __restrict__ valid, int C,
+                                                       int Hin, int Win, int pad, int reflect) {
+    const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Hin * Win) return;
+    float* gp_in = gin + (size_t)plane * Hin * Win;
+    if (valid != nullptr && valid[n] == 0) { gp_in[e] = 0.f; return; }
+    const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    const int jy = e / Win, jx = e - jy * Win;
+    float wk[K * K];
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = w[(size_t)c * K * K + k];
+    const float* gp = gout + (size_t)plane * Ho * Wo;
+    const bool rf = reflect && pad >= 1;
+    // per dimension: for each tap k the (up to 2 regular+mirrored) output indices
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        // candidates qy in {jy, mirror}: ty = qy + pad - ky must be >= 0, divisible by S, < Ho*S
+        int oys[2];
+        int ny = 0;
+        {
+            const int ty = jy + pad - ky;
+            if (ty >= 0 && ty % S == 0 && ty / S < Ho) oys[ny++] = ty / S;
+            int qm = -2;
+            if (rf && jy == 1) qm = -1;
+            if (rf && jy == Hin - 2) qm = Hin;
+            if (qm != -2) {
+                const int tm = qm + pad - ky;
+                if (tm >= 0 && tm % S == 0 && tm / S < Ho) oys[ny++] = tm / S;
             }
         }
-        out[e] = acc;
-    }
-}
-
-__device__ __forceinline__ int preimages(int j, int n, int pad, int reflect, int* q) {
-    int k = 0;
-    q[k++] = j;
-    if (reflect && pad >= 1) {
-        if (j == 1) q[k++] = -1;
-        if (j == n - 2) q[k++] = n;
-    }
-    return k;
-}
-
-__global__ void dw_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w, float* __restrict__ gin,
-                                const int* __restrict__ valid, int N, int C, int Hin, int Win, int K, int S, int pad,
-                                int reflect) {
-    const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
-    const long total = (long)N * C * Hin * Win;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int jx = (int)(e % Win);
-        long r = e / Win;
-        const int jy = (int)(r % Hin); r /= Hin;
-        const int c = (int)(r % C), n = (int)(r / C);
-        if (valid != nullptr && valid[n] == 0) { gin[e] = 0.f; continue; }
-        const float* gp = gout + ((size_t)n * C + c) * Ho * Wo;
-        const float* wp = w + (size_t)c * K * K;
-        int qy[3], qx[3];
-        const int ny = preimages(jy, Hin, pad, reflect, qy), nx = preimages(jx, Win, pad, reflect, qx);
-        float acc = 0.f;
-        for (int a = 0; a < ny; ++a)
-            for (int ky = 0; ky < K; ++ky) {
-                const int ty = qy[a] + pad - ky;
-                if (ty < 0 || ty % S != 0 || ty / S >= Ho) continue;
-                for (int b = 0; b < nx; ++b)
-                    for (int kx = 0; kx < K; ++kx) {
-                        const int tx = qx[b] + pad - kx;
-                        if (tx < 0 || tx % S != 0 || tx / S >= Wo) continue;
-                        acc += wp[ky * K + kx] * gp[(ty / S) * Wo + tx / S];
-                    }
+        if (ny == 0) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            int oxs[2];
+            int nx = 0;
+            const int tx = jx + pad - kx;
+            if (tx >= 0 && tx % S == 0 && tx / S < Wo) oxs[nx++] = tx / S;
+            int qm = -2;
+            if (rf && jx == 1) qm = -1;
+            if (rf && jx == Win - 2) qm = Win;
+            if (qm != -2) {
+                const int tm = qm + pad - kx;
+                if (tm >= 0 && tm % S == 0 && tm / S < Wo) oxs[nx++] = tm / S;
             }
-        gin[e] = acc;
+            const float wv = wk[ky * K + kx];
+            for (int a = 0; a < ny; ++a)
+                for (int bb = 0; bb < nx; ++bb) acc = fmaf(wv, gp[oys[a] * Wo + oxs[bb]], acc);
+        }
     }
+    gp_in[e] = acc;
 }
 
 // partial[n][c][k] : one workgroup per (n, c)
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                        float* __restrict__ partial, const int* __restrict__ valid, int C,
-                                                       int Hin, int Win, int K, int S, int pad, int reflect) {
-    __shared__ float red[4][16];
-    const int n = blockIdx.x / C, c = blockIdx.x % C;
+                                                       int Hin, int Win, int pad, int reflect) {
+    __shared__ float red[4][K * K];
+    const int n = blockIdx.x / C;
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
-    float acc[16];
+    float acc[K * K];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int k = 0; k < K * K; ++k) acc[k] = 0.f;
     if (valid == nullptr || valid[n] != 0) {
-        const float* ip = in + ((size_t)n * C + c) * Hin * Win;
-        const float* gp = gout + ((size_t)n * C + c) * Ho * Wo;
+        const float* ip = in + (size_t)blockIdx.x * Hin * Win;
+        const float* gp = gout + (size_t)blockIdx.x * Ho * Wo;
         for (int e = threadIdx.x; e < Ho * Wo; e += 256) {
-            const int oy = e / Wo, ox = e % Wo;
+            const int oy = e / Wo, ox = e - oy * Wo;
             const float g = gp[e];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < K * K) {
-                    int gy = oy * S - pad + k / K, gx = ox * S - pad + k % K;
-                    bool ok = true;
-                    if (reflect) { gy = reflect_idx(gy, Hin); gx = reflect_idx(gx, Win); }
-                    else ok = gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
-                    if (ok) acc[k] += g * ip[gy * Win + gx];
+            for (int ky = 0; ky < K; ++ky) {
+                int gy = oy * S - pad + ky;
+                bool oky = true;
+                if (reflect) gy = reflect_idx(gy, Hin); else oky = gy >= 0 && gy < Hin;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    int gx = ox * S - pad + kx;
+                    bool ok = oky;
+                    if (reflect) gx = reflect_idx(gx, Win); else ok = ok && gx >= 0 && gx < Win;
+                    const float v = ip[ok ? gy * Win + gx : 0];
+                    acc[ky * K + kx] = fmaf(g, ok ? v : 0.f, acc[ky * K + kx]);
                 }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < K * K; ++k) {
         const float s = wave_sum(acc[k]);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
     }
@@ -253,7 +282,7 @@ extern "C" int c2s_frame_flags(const float* x, int* valid, int N, long frame_ele
 
 static int dw_check(int N, int C, int Hin, int Win, int K, int S, int pad, int pad_mode) {
     C2S_REQUIRE(N > 0 && C > 0 && Hin > 0 && Win > 0, "dwconv: bad shape");
-    C2S_REQUIRE(K >= 1 && K <= 4 && S >= 1 && pad >= 0 && pad <= 1, "dwconv: unsupported kernel/stride/pad");
+    C2S_REQUIRE(((K == 3 && S == 1) || (K == 4 && S == 2)) && pad == 1, "dwconv: built for (K,S,pad) = (3,1,1) and (4,2,1)");
     if (pad_mode == C2S_PAD_REFLECT) C2S_REQUIRE(Hin >= 2 && Win >= 2, "dwconv: reflect needs planes >= 2x2");
     return C2S_OK;
 }
@@ -263,8 +292,13 @@ extern "C" int c2s_dwconv_fwd(const float* in, const float* w, float* out, const
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(in && w && out, "dwconv_fwd: null pointer");
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
-    hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_for((long)N * C * Ho * Wo, 16384)), dim3(256), 0, (hipStream_t)stream, in, w,
-                       out, valid, N, C, Hin, Win, K, S, pad, pad_mode == C2S_PAD_REFLECT);
+    const dim3 grid(cdiv(Ho * Wo, 256), N * C);
+    if (K == 3)
+        hipLaunchKernelGGL((dw_fwd_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, w, out, valid, C, Hin, Win, pad,
+                           pad_mode == C2S_PAD_REFLECT);
+    else
+        hipLaunchKernelGGL((dw_fwd_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, in, w, out, valid, C, Hin, Win, pad,
+                           pad_mode == C2S_PAD_REFLECT);
     C2S_CHECK_LAUNCH("dwconv_fwd");
     return C2S_OK;
 }
@@ -273,8 +307,13 @@ extern "C" int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, c
                                 int Win, int K, int S, int pad, int pad_mode, void* stream) {
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(gout && w && gin, "dwconv_dgrad: null pointer");
-    hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)N * C * Hin * Win, 16384)), dim3(256), 0, (hipStream_t)stream,
-                       gout, w, gin, valid, N, C, Hin, Win, K, S, pad, pad_mode == C2S_PAD_REFLECT);
+    const dim3 grid(cdiv(Hin * Win, 256), N * C);
+    if (K == 3)
+        hipLaunchKernelGGL((dw_dgrad_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, gout, w, gin, valid, C, Hin, Win,
+                           pad, pad_mode == C2S_PAD_REFLECT);
+    else
+        hipLaunchKernelGGL((dw_dgrad_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, gout, w, gin, valid, C, Hin, Win,
+                           pad, pad_mode == C2S_PAD_REFLECT);
     C2S_CHECK_LAUNCH("dwconv_dgrad");
     return C2S_OK;
 }
@@ -284,8 +323,12 @@ extern "C" int c2s_dwconv_wgrad(const float* in, const float* gout, float* parti
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(in && gout && partial && gw, "dwconv_wgrad: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(N * C), dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, K, S, pad,
-                       pad_mode == C2S_PAD_REFLECT);
+    if (K == 3)
+        hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(N * C), dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad,
+                           pad_mode == C2S_PAD_REFLECT);
+    else
+        hipLaunchKernelGGL((dw_wgrad_kernel<4, 2>), dim3(N * C), dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad,
+                           pad_mode == C2S_PAD_REFLECT);
     C2S_CHECK_LAUNCH("dwconv_wgrad");
     hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv(C * K * K, 256)), dim3(256), 0, st, partial, gw, N, C * K * K);
     C2S_CHECK_LAUNCH("dwconv_wgrad_reduce");
