@@ -38,7 +38,7 @@ class NormDesc(C.Structure):
 class LtaeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("n_head", C.c_int),
                 ("d_model", C.c_int), ("eps", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
-                ("keep", C.c_void_p)]
+                ("keep", C.c_void_p), ("seed_dev", C.c_void_p)]
 
 
 class AggDesc(C.Structure):
@@ -72,7 +72,7 @@ SIGNATURES = {
     "c2s_ltae_attn_fwd": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P]),
     "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_bwd": (I, [C.POINTER(LtaeDesc)] + [P] * 22 + [SZ, P]),
-    "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P]),
+    "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P, P]),
     "c2s_pixel_gn_fwd": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "c2s_pixel_gn_bwd_workspace_floats": (SZ, [I, I, I]),
     "c2s_pixel_gn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
@@ -81,7 +81,7 @@ SIGNATURES = {
     "c2s_temporal_aggregate_bwd": (I, [C.POINTER(AggDesc), P, P, P, P, P, I, P, P, SZ, P]),
     "c2s_cross_entropy_workspace_floats": (SZ, [I, I]),
     "c2s_cross_entropy": (I, [P, P, P, P, P, I, I, I, P, SZ, P]),
-    "c2s_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "c2s_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P, F, P]),
     "c2s_fill": (I, [P, L, F, P]),
     "c2s_add_inplace": (I, [P, P, L, P]),
 }

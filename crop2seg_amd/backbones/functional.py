@@ -48,6 +48,7 @@ class DropoutState:
     mlp_seed: int = 0
     attn_keep: Optional[Tensor] = None    # [n_head, P, T]
     mlp_keep: Optional[Tensor] = None     # [P, C']
+    seed_dev: Optional[Tensor] = None     # device uint64 step counter mixed into both seeds (hipGraph replay)
 
 
 def _mode(spec: BackboneSpec) -> int:
@@ -113,12 +114,12 @@ def up_conv_block(ctx, x, skip, prefix, spec):
 def ltae(ctx, x5, dates, valid, prefix, spec: BackboneSpec, drop: DropoutState, with_tail: bool):
     """LTAE.forward / LTAE4WTAE.forward (reference tae.py:451-504, 589-635)."""
     emb, attn = E.ltae_attention(ctx, x5, dates, valid, prefix, spec.n_head, spec.d_k, spec.d_model, spec.pe_period,
-                                 spec.attn_dropout, with_tail, drop.attn_seed, drop.attn_keep)
+                                 spec.attn_dropout, with_tail, drop.attn_seed, drop.attn_keep, drop.seed_dev)
     if not with_tail:
         return None, attn
     o = E.conv2d(ctx, [emb], prefix + ".mlp.0.weight", prefix + ".mlp.0.bias", 1, 1, 0, _lib.PAD_ZEROS, None)
     o = E.norm_act(ctx, o, prefix + ".mlp.2", _lib.NORM_BATCH, 1, True, None, None, conv_bias=prefix + ".mlp.0.bias")
-    o = E.dropout_nchw(ctx, o, spec.mlp_dropout, drop.mlp_seed, drop.mlp_keep)
+    o = E.dropout_nchw(ctx, o, spec.mlp_dropout, drop.mlp_seed, drop.mlp_keep, drop.seed_dev)
     o = E.pixel_group_norm(ctx, o, prefix + ".out_norm", spec.n_head)
     return o, attn
 

@@ -32,6 +32,7 @@ struct LtaeParams {
     int B, T, C, HW;
     float eps, drop_p;
     uint64_t seed;
+    const uint64_t* seed_dev;   // optional device-side step counter added to the seed (hipGraph replay)
 };
 
 __device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_total, long pidx, int t) {
@@ -39,7 +40,8 @@ __device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_t
     const long idx = ((long)h * P_total + pidx) * p.T + t;
     const float inv = 1.f / (1.f - p.drop_p);
     if (p.keep != nullptr) return p.keep[idx] != 0.f ? inv : 0.f;
-    return c2s_uniform(p.seed, (uint64_t)idx) >= p.drop_p ? inv : 0.f;
+    const uint64_t seed = p.seed + (p.seed_dev != nullptr ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+    return c2s_uniform(seed, (uint64_t)idx) >= p.drop_p ? inv : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -637,7 +639,8 @@ __global__ __launch_bounds__(64) void pixel_gn_bwd_kernel(const float* __restric
 
 // y[b,c,pix] = x * keep / (1-p), keep indexed pixel-major like the reference's [P, C] activations (tae.py:448)
 __global__ void dropout_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW, float p,
-                                    uint64_t seed, const float* __restrict__ keep) {
+                                    uint64_t seed0, const uint64_t* __restrict__ seed_dev, const float* __restrict__ keep) {
+    const uint64_t seed = seed0 + (seed_dev != nullptr ? *seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const long total = (long)B * C * HW;
     const float inv = 1.f / (1.f - p);
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -676,7 +679,7 @@ int check(const c2s_ltae_desc* d) {
 }
 
 void fill(LtaeParams& p, const c2s_ltae_desc* d) {
-    p.B = d->B; p.T = d->T; p.C = d->C; p.HW = d->HW; p.eps = d->eps; p.drop_p = d->dropout_p; p.seed = d->seed;
+    p.B = d->B; p.T = d->T; p.C = d->C; p.HW = d->HW; p.eps = d->eps; p.drop_p = d->dropout_p; p.seed = d->seed; p.seed_dev = d->seed_dev;
     p.keep = d->keep;
 }
 
@@ -813,12 +816,13 @@ extern "C" int c2s_pixel_gn_bwd(const float* x, const float* gy, const float* ga
     return C2S_OK;
 }
 
-extern "C" int c2s_dropout_nchw(const float* x, float* y, int B, int C, int HW, float p, uint64_t seed, const float* keep,
+extern "C" int c2s_dropout_nchw(const float* x, float* y, int B, int C, int HW, float p, uint64_t seed,
+                                const uint64_t* seed_dev, const float* keep,
                                 void* stream) {
     C2S_REQUIRE(x && y && p >= 0.f && p < 1.f, "dropout: bad args");
     const long total = (long)B * C * HW;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(dropout_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, C, HW, p, seed, keep);
+    hipLaunchKernelGGL(dropout_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, C, HW, p, seed, seed_dev, keep);
     C2S_CHECK_LAUNCH("dropout");
     return C2S_OK;
 }

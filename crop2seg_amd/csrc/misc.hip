@@ -242,8 +242,12 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 
 // ---------------------------------------------------------------- Adam (train.py:454, torch defaults)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1, float bc2s,
-                            float gscale) {
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, int step,
+                            const int* __restrict__ step_dev, float gscale) {
+    // the step count may live on the device so that a captured graph advances it on replay
+    const int st = step_dev != nullptr ? *step_dev : step;
+    const float bc1 = 1.f - powf(b1, (float)st);
+    const float bc2s = sqrtf(1.f - powf(b2, (float)st));
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gg = g[i] * gscale;
         const float mm = b1 * m[i] + (1.f - b1) * gg;
@@ -359,12 +363,10 @@ extern "C" int c2s_cross_entropy(const float* logits, const int64_t* target, con
 }
 
 extern "C" int c2s_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                             float eps, int step, float grad_scale, void* stream) {
-    C2S_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad args");
-    const float bc1 = 1.f - powf(b1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+                             float eps, int step, const int* step_dev, float grad_scale, void* stream) {
+    C2S_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev != nullptr), "adam: bad args");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2,
-                       eps, bc1, bc2s, grad_scale);
+                       eps, step, step_dev, grad_scale);
     C2S_CHECK_LAUNCH("adam");
     return C2S_OK;
 }

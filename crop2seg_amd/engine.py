@@ -425,8 +425,8 @@ def temporal_aggregate(ctx: Ctx, x5: Tensor, attn: Tensor, valid: Optional[Tenso
 def positional_table(dates: Tensor, d: int, period: float) -> Tensor:
     """[B,T] int days -> [B,T,d] sinusoid table (reference positional_encoding.py:16-33); host-side table."""
     i = torch.arange(d, device=dates.device, dtype=torch.float32)
-    denom = torch.pow(torch.tensor(period, device=dates.device, dtype=torch.float32),
-                      2 * torch.div(i, 2, rounding_mode="floor") / d)
+    # scalar ** tensor: no host->device copy (the call must stay hipGraph-capturable)
+    denom = torch.pow(float(period), 2 * torch.div(i, 2, rounding_mode="floor") / d)
     tab = dates.to(torch.float32)[:, :, None] / denom[None, None, :]
     out = torch.empty_like(tab)
     out[..., 0::2] = torch.sin(tab[..., 0::2])
@@ -451,7 +451,7 @@ def _fold_attention_params(Q: Tensor, Wk: Tensor, bk: Tensor, Wc: Tensor, bc: Te
 
 def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor], prefix: str, n_head: int, d_k: int,
                    d_model: int, period: float, dropout_p: float, with_embedding: bool, seed: int,
-                   keep: Optional[Tensor]) -> Tuple[Optional[Tensor], Tensor]:
+                   keep: Optional[Tensor], seed_dev: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor]:
     """L-TAE steps 1-6 (reference tae.py:451-481, 738-847).  Returns (emb [B,d_model,h,w] | None, attn [H,B,T,h,w])."""
     B, T, Cc, h, w = x5.shape
     HW = h * w
@@ -472,7 +472,7 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
             U, s0 = _fold_attention_params(Q, Wk, bk, Wc3[:, :, 0], bc, pe, n_head, d_k)
     Wc = Wc3.view(d_model, Cc)
     p_eff = dropout_p if ctx.training else 0.0
-    d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None)
+    d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None, _ptr(seed_dev))
     attn = torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
     attn_pre = torch.empty_like(attn) if ctx.tape is not None else None
     emb = torch.empty(B, d_model, h, w, device=x5.device, dtype=torch.float32) if with_embedding else None
@@ -523,14 +523,14 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     return emb, attn
 
 
-def dropout_nchw(ctx: Ctx, x: Tensor, p: float, seed: int, keep: Optional[Tensor]) -> Tensor:
+def dropout_nchw(ctx: Ctx, x: Tensor, p: float, seed: int, keep: Optional[Tensor], seed_dev: Optional[Tensor] = None) -> Tensor:
     """nn.Dropout of the L-TAE MLP (reference tae.py:448); identity in eval mode."""
     if not ctx.training or p <= 0.0:
         return x
     B, Cc = x.shape[:2]
     HW = x[0, 0].numel()
     y = torch.empty_like(x)
-    check(lib().c2s_dropout_nchw(x.data_ptr(), y.data_ptr(), B, Cc, HW, p, seed, _ptr(keep), _stream()), "dropout")
+    check(lib().c2s_dropout_nchw(x.data_ptr(), y.data_ptr(), B, Cc, HW, p, seed, _ptr(seed_dev), _ptr(keep), _stream()), "dropout")
     if ctx.tape is not None:
         tape = ctx.tape
         tape.track(y)
@@ -540,7 +540,7 @@ def dropout_nchw(ctx: Ctx, x: Tensor, p: float, seed: int, keep: Optional[Tensor
             if g is None:
                 return
             gx = torch.empty_like(g)
-            check(lib().c2s_dropout_nchw(g.data_ptr(), gx.data_ptr(), B, Cc, HW, p, seed, _ptr(keep), _stream()),
+            check(lib().c2s_dropout_nchw(g.data_ptr(), gx.data_ptr(), B, Cc, HW, p, seed, _ptr(seed_dev), _ptr(keep), _stream()),
                   "dropout_bwd")
             tape.add_grad(x, gx)
 
@@ -597,6 +597,6 @@ def cross_entropy(logits: Tensor, target: Tensor, class_w: Tensor, ws: Workspace
 
 
 def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float = 1e-3, b1: float = 0.9,
-              b2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+              b2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0, step_dev: Optional[Tensor] = None) -> None:
     check(lib().c2s_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps, step,
-                              grad_scale, _stream()), "adam")
+                              _ptr(step_dev), grad_scale, _stream()), "adam")

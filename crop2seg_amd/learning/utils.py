@@ -117,28 +117,37 @@ class TrainStep:
             self.dp = FlatDataParallel(process_group)
             self.dp.sync_parameters(self.flat_param)                      # identical initial weights on every rank
 
-    @torch.no_grad()
-    def __call__(self, x: Tensor, dates: Tensor, y: Tensor, dropout_state: Optional[Fn.DropoutState] = None,
-                 apply_update: bool = True) -> Tuple[Tensor, Tensor]:
-        """Returns (loss[1] device tensor, logits).  No host synchronisation inside."""
+    # ------------------------------------------------------------------------------------------------
+    def _forward_backward(self, x: Tensor, dates: Tensor, y: Tensor, drop: Fn.DropoutState) -> Tuple[Tensor, Tensor]:
+        """zero_grad -> forward -> CE -> backward into the flat gradient buffer (stream-ordered, no host sync)."""
         model = self.model
-        model._check_inputs(x, dates)
-        drop = dropout_state
-        if drop is None:
-            drop = Fn.DropoutState()
-            if model.training:
-                self.step_count_seed = getattr(self, "step_count_seed", 0) + 1
-                base = (torch.initial_seed() * 0x9E3779B1 + self.step_count_seed * 2) & ((1 << 62) - 1)
-                drop.attn_seed, drop.mlp_seed = base, base + 1
         tape = E.Tape()
         ctx = E.Ctx(self.params, dict(model.named_buffers()), self.grads, self.ws, model.training, tape)
-        logits, _att = Fn.FORWARDS[model.spec.model](ctx, model.spec, x.contiguous(), dates.contiguous(), drop)
+        logits, _att = Fn.FORWARDS[model.spec.model](ctx, model.spec, x, dates, drop)
         loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True)
         tape.grads[logits.data_ptr()] = glogits
         tape.backward()
         for n in self.names:                             # parameters no kernel wrote to (none in the default models)
             if n not in ctx._gwritten:
                 self.grads[n].zero_()
+        return loss, logits
+
+    def _fresh_dropout(self) -> Fn.DropoutState:
+        drop = Fn.DropoutState()
+        if self.model.training:
+            self._seed_calls = getattr(self, "_seed_calls", 0) + 1
+            rank = self.dp.rank if self.dp is not None else 0
+            base = (torch.initial_seed() * 0x9E3779B1 + self._seed_calls * 2 + rank * 0x51ED27) & ((1 << 62) - 1)
+            drop.attn_seed, drop.mlp_seed = base, base + 1
+        return drop
+
+    @torch.no_grad()
+    def __call__(self, x: Tensor, dates: Tensor, y: Tensor, dropout_state: Optional[Fn.DropoutState] = None,
+                 apply_update: bool = True) -> Tuple[Tensor, Tensor]:
+        """Eager step.  Returns (loss[1] device tensor, logits).  No host synchronisation inside."""
+        self.model._check_inputs(x, dates)
+        drop = dropout_state if dropout_state is not None else self._fresh_dropout()
+        loss, logits = self._forward_backward(x.contiguous(), dates.contiguous(), y, drop)
         scale = 1.0
         if self.dp is not None:
             scale = self.dp.reduce_gradients(self.flat_grad)              # one 4.3 MB bucket per step
@@ -147,3 +156,51 @@ class TrainStep:
             E.adam_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                         self.betas[0], self.betas[1], self.eps, grad_scale=scale)
         return loss, logits
+
+    # ------------------------------------------------------------------------------------------------
+    # hipGraph path: the whole step (about 1,100 kernel launches, ~9 ms of host time when launched eagerly) is
+    # captured once and replayed.  Everything the step needs to vary between replays lives on the device: the
+    # dropout seed offset and the Adam step count are device counters advanced inside the graph.
+    @torch.no_grad()
+    def capture(self, x: Tensor, dates: Tensor, y: Tensor) -> None:
+        """Capture the step for inputs of this shape.  `x`, `dates`, `y` are copied into static buffers; call
+        `replay(x, dates, y)` (or `replay()` to reuse the buffers' content) afterwards."""
+        self.model._check_inputs(x, dates)
+        dev = x.device
+        self.static_x, self.static_dates, self.static_y = x.clone().contiguous(), dates.clone().contiguous(), y.clone()
+        self.step_dev = torch.full((1,), self.step_count, device=dev, dtype=torch.int32)
+        self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        drop = self._fresh_dropout()
+        drop.seed_dev = self.seed_dev
+        saved = {k: v.clone() for k, v in self.model.named_buffers()}     # the warm-up pass must not count as a step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up on the side stream: lazy one-time initialisation
+            self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)   # (function attributes, workspaces)
+        torch.cuda.current_stream().wait_stream(side)
+        for k, v in self.model.named_buffers():
+            v.copy_(saved[k])
+        torch.cuda.synchronize()
+        scale = 1.0 / self.dp.world if self.dp is not None else 1.0
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb):
+            self.seed_dev.add_(1)
+            self.static_loss, self.static_logits = self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)
+        self.graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_opt):
+            self.step_dev.add_(1)
+            E.adam_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, 0, self.lr, self.betas[0],
+                        self.betas[1], self.eps, grad_scale=scale, step_dev=self.step_dev)
+
+    @torch.no_grad()
+    def replay(self, x: Optional[Tensor] = None, dates: Optional[Tensor] = None, y: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if x is not None:
+            self.static_x.copy_(x)
+            self.static_dates.copy_(dates)
+            self.static_y.copy_(y)
+        self.graph_fb.replay()
+        if self.dp is not None:
+            self.dp.reduce_gradients(self.flat_grad)          # between the two graphs, on the same stream
+        self.graph_opt.replay()
+        self.step_count += 1
+        return self.static_loss, self.static_logits

@@ -170,6 +170,8 @@ typedef struct c2s_ltae_desc {
     float dropout_p;      /* 0 => no dropout */
     uint64_t seed;        /* dropout RNG key */
     const float* keep;    /* optional explicit keep mask [16,P,T] (tests); NULL => RNG when dropout_p>0 */
+    const uint64_t* seed_dev; /* optional DEVICE counter mixed into the seed (advanced by the caller between
+                                 hipGraph replays so that every step draws a fresh mask); NULL => seed only */
 } c2s_ltae_desc;
 
 int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
@@ -188,8 +190,8 @@ int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const float* gamma
  * (c2s_conv_igemm), BatchNorm1d over P is c2s_norm_* with kind BATCH; the two pieces below are the rest:
  * Dropout(0.2) with the keep mask indexed pixel-major [P,C] like the reference's activations, and the
  * per-pixel GroupNorm(16) over channel groups (out_norm). */
-int c2s_dropout_nchw(const float* x, float* y, int B, int C, int HW, float p, uint64_t seed, const float* keep,
-                     void* stream);
+int c2s_dropout_nchw(const float* x, float* y, int B, int C, int HW, float p, uint64_t seed, const uint64_t* seed_dev,
+                     const float* keep, void* stream);
 int c2s_pixel_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int B, int C,
                      int HW, int groups, float eps, void* stream);
 size_t c2s_pixel_gn_bwd_workspace_floats(int B, int C, int HW);
@@ -225,8 +227,10 @@ int c2s_temporal_aggregate_bwd(const c2s_agg_desc* d, const float* x, const floa
 size_t c2s_cross_entropy_workspace_floats(int B, int HW);
 int c2s_cross_entropy(const float* logits, const int64_t* target, const float* class_w, float* loss,
                       float* glogits, int B, int K, int HW, float* workspace, size_t ws_floats, void* stream);
+/* step_dev: optional DEVICE int holding the 1-based step count (takes precedence over `step`; lets a captured
+ * hipGraph advance the bias correction on replay) */
 int c2s_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                  int step, float grad_scale, void* stream);
+                  int step, const int* step_dev, float grad_scale, void* stream);
 
 /* elementwise helpers */
 int c2s_fill(float* p, long n, float v, void* stream);

@@ -141,3 +141,41 @@ def test_full_size_properties():
     assert float(logits.min()) >= 0.0
     assert float(att[:, 1, 27:].abs().max()) == 0.0
     assert torch.equal(l0[0], logits[0]) and torch.equal(a0[:, 0], att[:, 0])
+
+
+def test_hipgraph_replay_equals_eager(goldens):
+    """The captured step (two hipGraphs: fwd+CE+bwd, Adam) replays bit-identically to eager launches, advances the
+    Adam step count on the device, and draws a fresh dropout mask on every replay."""
+    import copy
+    from crop2seg_amd.learning.utils import TrainStep
+    g = goldens("utae_train_p0_tame")
+    x, dates, y = g.x.cuda(), g.dates.cuda(), g.y.cuda()
+
+    def fresh(p_drop):
+        net, _ = build(g)
+        net.train()
+        net.spec.attn_dropout = p_drop
+        net.spec.mlp_dropout = p_drop
+        return net, TrainStep(net, num_classes=15)
+
+    net_e, step_e = fresh(0.0)
+    for _ in range(3):
+        loss_e, _ = step_e(x, dates, y)
+    net_g, step_g = fresh(0.0)
+    step_g(x, dates, y)                      # step 1 eager
+    step_g.capture(x, dates, y)
+    for _ in range(2):                       # steps 2, 3 replayed
+        loss_g, _ = step_g.replay()
+    torch.cuda.synchronize()
+    assert float(loss_g) == float(loss_e)
+    assert torch.equal(step_g.flat_param, step_e.flat_param), "replayed parameters differ from eager ones"
+    assert int(step_g.step_dev) == 3
+    for k, v in net_e.state_dict().items():
+        assert torch.equal(v, net_g.state_dict()[k]), k
+    # dropout on: consecutive replays must not reuse the mask
+    net_d, step_d = fresh(0.3)
+    step_d.capture(x, dates, y)
+    step_d.lr = 0.0
+    l1 = float(step_d.replay()[0])
+    l2 = float(step_d.replay()[0])
+    assert l1 != l2
