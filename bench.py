@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3"],
+                    help="convolution arithmetic: exact fp32 MFMA (default) or opt-in split-precision bf16x3")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -106,6 +108,8 @@ def main():
     from crop2seg_amd import engine as E
     from crop2seg_amd.learning.utils import TrainStep, default_config, get_model
 
+    if args.conv_mode is not None:
+        E.CONV_MODE = args.conv_mode
     torch.manual_seed(1)                                   # --rdm_seed 1 (reference train.py:113,616-618)
     net = get_model(default_config(args.model)).to(device)
     net.apply(C2S.weight_init)                             # after .to(device), as in train.py:447-450
@@ -177,7 +181,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if E.CONV_MODE == "f32" else "bf16x3 (split-fp32 operands on bf16 MFMA, fp32 accumulate) + f32",
             "data": "synthetic",
             "config": {"workload": f"{args.model} train step (fwd+CE+bwd+Adam, train mode), B={B}/GPU T={T} 10x{H}x{H}, "
                                    f"random-init weight_init weights, BASELINE.json configs[1] shape in fp32",

@@ -130,6 +130,25 @@ class Ctx:
         return wpk, coutP
 
 
+def _pack_bf16x3(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, cout: int, so: int, sc: int,
+                 taps: Sequence[int]) -> Tuple[Tensor, Tensor, int]:
+    hit = ctx._packed.get(key)
+    coutP = (cout + 31) // 32 * 32
+    if hit is not None:
+        return hit[0], hit[1], coutP
+    n = lib().c2s_bf16x3_packed_elems(cin, coutP)
+    whi = torch.empty(n, device=ctx.device, dtype=torch.bfloat16)
+    wlo = torch.empty(n, device=ctx.device, dtype=torch.bfloat16)
+    check(lib().c2s_pack_weights_bf16x3(src.data_ptr() + 4 * src_off, whi.data_ptr(), wlo.data_ptr(), cin, cout, coutP,
+                                        len(taps), so, sc, _tap_array(taps), _stream()), "pack_weights_bf16x3")
+    ctx._packed[key] = (whi, wlo)
+    return whi, wlo, coutP
+
+
+def _use_bf16x3(K: int, S: int, pad: int, chans: Sequence[int]) -> bool:
+    return CONV_MODE == "bf16x3" and K == 3 and S == 1 and pad == 1 and all(c % 8 == 0 for c in chans)
+
+
 # =================================================================================================
 # frame flags
 # =================================================================================================
@@ -145,6 +164,14 @@ def frame_flags(x5: Tensor, pad_value: float) -> Tensor:
 # =================================================================================================
 # convolutions
 # =================================================================================================
+# Convolution arithmetic: "f32" = exact fp32 MFMA everywhere (default); "bf16x3" = split-precision bf16 MFMA
+# (three products per fp32 product, fp32 accumulate, ~1e-5 relative) for the 3x3 stride-1 forward / data-gradient
+# launches whose channel counts are multiples of 8; everything else stays on the exact kernels.
+import os as _os
+
+CONV_MODE = _os.environ.get("C2S_CONV_MODE", "f32")
+assert CONV_MODE in ("f32", "bf16x3"), CONV_MODE
+
 # bench.py sets PROFILE = {"match": {field: value}, "events": []}: launches whose descriptor matches are bracketed
 # with HIP events on the launch stream (the stream the kernel runs on) for the live roofline measurement.
 PROFILE: Optional[dict] = None
@@ -205,10 +232,17 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     Ho = (Hin + 2 * pad - K) // S + 1
     Wo = (Win + 2 * pad - K) // S + 1
     KK = K * K
-    wpk, CoutP = ctx.pack((wname, "fwd"), W, 0, Cin, Cout, KK, Cin * KK, KK, list(range(KK)))
     out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
-    d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
-    _igemm(d, s0, s1, wpk, ctx.p[bname] if bname else None, out, valid)
+    if _use_bf16x3(K, S, pad, [C0, C1]):
+        whi, wlo, CoutP = _pack_bf16x3(ctx, (wname, "fwd", "bx"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)))
+        d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
+        check(lib().c2s_conv3x3_bf16x3(C.byref(d), s0.data_ptr(), _ptr(s1), whi.data_ptr(), wlo.data_ptr(),
+                                       _ptr(ctx.p[bname] if bname else None), out.data_ptr(), _ptr(valid), _stream()),
+              "conv3x3_bf16x3")
+    else:
+        wpk, CoutP = ctx.pack((wname, "fwd"), W, 0, Cin, Cout, KK, Cin * KK, KK, list(range(KK)))
+        d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
+        _igemm(d, s0, s1, wpk, ctx.p[bname] if bname else None, out, valid)
     if ctx.tape is None:
         return out
     tape = ctx.tape
@@ -231,10 +265,17 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             radj = 1 if (pad_mode == _lib.PAD_REFLECT and pad > 0) else 0   # reflection adjoint folded into the kernel
             if S == 1:
                 taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
-                wd, CP = ctx.pack((wname, "dgrad", si), W, c_lo * KK, Cout, Cs, KK, KK, Cin * KK, taps)
-                dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, K - 1 - pad, K - 1 - pad,
-                              _lib.PAD_ZEROS, 1, 1, 0, 0, accf, radj)
-                _igemm(dd, g, None, wd, None, gin, valid)
+                if _use_bf16x3(K, S, pad, [Cout]):
+                    whi, wlo, CP = _pack_bf16x3(ctx, (wname, "dgrad", "bx", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps)
+                    dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
+                                  accf, radj)
+                    check(lib().c2s_conv3x3_bf16x3(C.byref(dd), g.data_ptr(), None, whi.data_ptr(), wlo.data_ptr(), None,
+                                                   gin.data_ptr(), _ptr(valid), _stream()), "conv3x3_bf16x3")
+                else:
+                    wd, CP = ctx.pack((wname, "dgrad", si), W, c_lo * KK, Cout, Cs, KK, KK, Cin * KK, taps)
+                    dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, K - 1 - pad, K - 1 - pad,
+                                  _lib.PAD_ZEROS, 1, 1, 0, 0, accf, radj)
+                    _igemm(dd, g, None, wd, None, gin, valid)
             else:
                 assert K == 4 and S == 2 and pad == 1
                 for py in range(2):

@@ -83,6 +83,20 @@ int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const float* src1,
                    const float* bias, float* out, const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Opt-in split-precision variant of the 3x3 stride-1 pad-1 convolution (forward and data gradient, same
+ * descriptor as c2s_conv_igemm): every fp32 operand is split into two bf16 halves (hi + lo, 16 significant bits)
+ * and each product evaluated with three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi) accumulating in fp32
+ * ("bf16x3"): ~1e-5 relative accuracy at ~5x the rate of the exact fp32 MFMA.  Weights are pre-split by
+ * c2s_pack_weights_bf16x3 into two bf16 arrays of c2s_bf16x3_packed_elems(cin, coutP) elements each
+ * ([cin/8][10 taps][coutP][8]).  Channel counts must be multiples of 8.
+ * ------------------------------------------------------------------------------------------------ */
+size_t c2s_bf16x3_packed_elems(int cin, int coutP);
+int c2s_pack_weights_bf16x3(const float* src, void* whi, void* wlo, int cin, int cout, int coutP, int ntaps,
+                            long stride_o, long stride_c, const int* host_tap_off, void* stream);
+int c2s_conv3x3_bf16x3(const c2s_conv_desc* d, const float* src0, const float* src1, const void* whi,
+                       const void* wlo, const float* bias, float* out, const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight gradient (convolution_backward-weight of the same call sites), split-K over output tiles:
  *   slab[s][t][c][o] = sum over the tiles of slice s of  in[n,c,map(oy*S+ky-pad),..] * gout[n,o,oy,ox]
  * followed by c2s_wgrad_reduce which sums the slices (fixed order: bitwise reproducible) and scatters to

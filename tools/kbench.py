@@ -31,8 +31,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--mode", default="f32", choices=["f32", "bf16x3"])
     args = ap.parse_args()
     dev = torch.device("cuda")
+    E.CONV_MODE = args.mode
     shapes = [  # name, N, Cin, Cout, H, K, S, pad, mode
         ("in_conv.3   64->64  3x3 @128", 128, 64, 64, 128, 3, 1, 1, L.PAD_REFLECT),
         ("in_conv.0   10->64  3x3 @128", 128, 10, 64, 128, 3, 1, 1, L.PAD_REFLECT),
