@@ -43,7 +43,8 @@ constexpr int max_plane(int K, int S) {
 
 template <int K, int S>
 struct Cfg {
-    static constexpr int CK = 4;
+    // channels per LDS chunk: enough MFMA k-steps per barrier pair (>= 16) without growing the prefetch registers
+    static constexpr int CK = K == 1 ? 16 : (K == 2 ? 8 : (K == 4 ? 2 : 4));
     static constexpr int NT = K * K;
     static constexpr int MAXE = (CK * max_plane(K, S) + 255) / 256;
 };
@@ -67,8 +68,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int tile_h = 8 * FR, tile_w = FC;
     const int rows = (tile_h - 1) * S + K, cols = (tile_w - 1) * S + K;
     const int plane = rows * cols;
-    float* Xl = lds;                 // [CK][plane]
-    float* Wl = lds + CK * plane;    // [NT][CK][COT]
+    float* Xl = lds;                 // [2][ [CK][plane] | [NT][CK][COT] ]
+    const int xsz = (CK * plane + 3) & ~3;
+    float* Wl = lds + xsz;
+    const int BUF = xsz + NT * CK * COT;
 
     const int tyi = blockIdx.x / p.tiles_x, txi = blockIdx.x % p.tiles_x;
     const int oy0 = tyi * tile_h, ox0 = txi * tile_w;
@@ -178,21 +181,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        float* Xd = Xl + buf * BUF;
+        float* Wd = Wl + buf * BUF;
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int e = tid + i * 256;
-            if (e < total) Xl[e] = xr[i];
+            if (e < total) Xd[e] = xr[i];
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int e = tid + i * 256;
-            if (e < NWV) *reinterpret_cast<f32x4*>(Wl + (size_t)e * 4) = wr[i];
+            if (e < NWV) *reinterpret_cast<f32x4*>(Wd + (size_t)e * 4) = wr[i];
         }
     };
 
     // operands of k-step s = (tap t, channel pair cp)
-    auto load_ops = [&](int s_, float (&a)[MF], float (&b)[2]) {
+    auto load_ops = [&](const float* Xl, const float* Wl, int s_, float (&a)[MF], float (&b)[2]) {
         const int t = s_ / (CK / 2), cp = s_ % (CK / 2);
         const int ky = t / K, kx = t % K;
 #pragma unroll
@@ -223,41 +228,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
     };
 
+    // K loop, LDS double-buffered: one barrier per chunk.  While chunk k is multiplied out of buffer k&1, the
+    // registers holding chunk k+1 (requested one chunk earlier) are committed to the other buffer and the request
+    // for chunk k+2 is issued, both in the middle of the MFMA sequence so that neither sits next to the barrier.
+    constexpr int COMMIT_AT = NS / 2;
     prefetch(0);
-    for (int cb = 0; cb < Cin; cb += CK) {
-        commit();
-        __syncthreads();
-        if (cb + CK < Cin) prefetch(cb + CK);       // in flight during the MFMA loop
-        // ---- MFMA: per tap, operand reads software-pipelined one k-step ahead; a scheduling barrier per tap keeps
-        // the compiler from hoisting the whole chunk's LDS reads (register pressure -> occupancy)
+    commit(0);
+    if (CK < Cin) prefetch(CK);
+    __syncthreads();
+    int cur = 0;
+    for (int cb = 0; cb < Cin; cb += CK, cur ^= 1) {
+        const float* Xc = Xl + cur * BUF;
+        const float* Wc = Wl + cur * BUF;
+        float a[2][MF], b[2][2];
+        load_ops(Xc, Wc, 0, a[0], b[0]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            constexpr int CP = CK / 2;
-            float a0[MF], b0[2], a1[MF], b1[2];
-            load_ops(t * CP, a0, b0);
+        for (int s_ = 0; s_ < NS; ++s_) {
+            // operands one k-step ahead; the scheduling barriers keep hipcc from sinking the ds_reads below the
+            // MFMAs that hide them (it would then wait on them right away) or hoisting a whole chunk's reads
+            if (s_ + 1 < NS) load_ops(Xc, Wc, s_ + 1, a[(s_ + 1) & 1], b[(s_ + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c2 = 0; c2 < CP; c2 += 2) {
-                // hipcc otherwise sinks the next step's ds_reads below these MFMAs and waits on them right away
-                if (c2 + 1 < CP) load_ops(t * CP + c2 + 1, a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < MF; ++m)
 #pragma unroll
-                for (int m = 0; m < MF; ++m)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[q], acc[m][q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c2 + 2 < CP) load_ops(t * CP + c2 + 2, a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c2 + 1 < CP) {
-#pragma unroll
-                    for (int m = 0; m < MF; ++m)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[q], acc[m][q], 0, 0, 0);
-                }
+                for (int q = 0; q < 2; ++q)
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][m], b[s_ & 1][q], acc[m][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s_ == COMMIT_AT && cb + CK < Cin) {
+                commit(cur ^ 1);
+                if (cb + 2 * CK < Cin) prefetch(cb + 2 * CK);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -309,7 +310,7 @@ int launch_conv(const ConvParams& p, int N, int tiles, hipStream_t st) {
     constexpr int NT = Cfg<K, S>::NT;
     const int FC = 1 << p.log2fc, FR = 32 >> p.log2fc;
     const int rows = (8 * FR - 1) * S + K, cols = (FC - 1) * S + K;
-    const size_t lds = ((size_t)CK * rows * cols + (size_t)NT * CK * 32 * MF) * sizeof(float);
+    const size_t lds = 2 * ((((size_t)CK * rows * cols + 3) & ~(size_t)3) + (size_t)NT * CK * 32 * MF) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<K, S, MF, ADJ>),

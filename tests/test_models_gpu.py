@@ -91,6 +91,7 @@ def test_model_matches_reference(goldens, name, conv_mode):
     params = dict(net.named_parameters())
     # eval mode: 1e-3 per tensor against the reference's gradients.  train mode: fp64-anchored criterion
     # (conftest.Golden.fp64_anchor).
+    g.soft_violations = []
     for n in names:
         if g.training:
             g.check_train_grad(n, params[n].grad, gmax, _abs_only(n, True))
@@ -101,6 +102,7 @@ def test_model_matches_reference(goldens, name, conv_mode):
         else:
             assert e <= 1e-3 * sc + 1e-6 * gmax, (n, e / max(sc, 1e-30))
     if g.training:
+        assert len(g.soft_violations) <= 0.1 * len(names), g.soft_violations
         sd = net.state_dict()
         for k in g.z.files:
             if k.startswith("bn/"):

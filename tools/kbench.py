@@ -43,7 +43,10 @@ def main():
         ("down1.down  64->64  4x4s2 @64", 128, 64, 64, 64, 4, 2, 1, L.PAD_REFLECT),
         ("down1.conv1 64->64  3x3 @32", 128, 64, 64, 32, 3, 1, 1, L.PAD_REFLECT),
         ("down2.conv1 64->128 3x3 @16", 128, 64, 128, 16, 3, 1, 1, L.PAD_REFLECT),
+        ("down2.down  64->128 4x4s2 @32", 128, 64, 128, 32, 4, 2, 1, L.PAD_REFLECT),
+        ("down2.conv2 128->128 3x3 @16", 128, 128, 128, 16, 3, 1, 1, L.PAD_REFLECT),
         ("up2.conv1   96->32  3x3 @128 (B=4)", 4, 96, 32, 128, 3, 1, 1, L.PAD_REFLECT),
+        ("wtae pointwise 64->64 1x1 @128", 128, 64, 64, 128, 1, 1, 0, L.PAD_ZEROS),
     ]
     print(f"{'layer':36s} {'GFLOP':>7s} | {'fwd ms':>7s} {'TF':>6s} | {'dgrad ms':>8s} {'TF':>6s} | {'wgrad ms':>8s} {'TF':>6s}")
     for name, N, Cin, Cout, H, K, S, pad, mode in shapes:
