@@ -162,45 +162,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Fast path (planes whose width is a multiple of 32: every full-resolution / half-resolution layer).
-// Same decomposition as conv_wgrad_kernel, but the tile is 32 positions wide so every row segment of the input
-// tile (32*S floats + 1 halo column each side) and of the gout tile (32 floats) is 128-byte aligned: global
-// traffic is float4, and the loads of tile i+1 are issued into registers BEFORE the MFMA loop of tile i
-// (register-staged software pipeline, cdna_hip_programming.md T14): HBM/L2 latency hides under ~20k cycles of MFMA.
-constexpr int FAST_TP = 128;  // positions per tile of the fast path (4 rows x 32)
-
+// Tiled path (planes whose width is 16 or a multiple of 32: every layer of the default models at 16..128 px).
+// The tile is TW = 32 or 16 positions wide so that every row segment of the input tile (TW*S floats + 1 halo column
+// each side) and of the gout tile (TW floats) is 16-byte aligned: global traffic is float4, and the loads of
+// tile i+1 are issued into registers BEFORE the MFMA loop of tile i (register-staged software pipeline,
+// cdna_hip_programming.md T14): HBM/L2 latency hides under ~20k cycles of MFMA.
+// Work split over the 4 waves (wave = (ofrag, half)):
+//   MODE 0 (4x4):  half = tap parity      -> 8 accumulators per wave, every wave walks all positions
+//   MODE 1 (3x3, 1x1): half = position half of the tile -> NT accumulators per wave (every wave the same number of
+//                  MFMAs per k-step; the tap-parity split of 9 taps is 5:4 and left one SIMD pair 20 % idle);
+//                  the two halves are added through LDS once, after the last tile
+//   MODE 2 (3x3, Cin <= 10, the first layer): as MODE 1 but the MFMA rows are (tap, cin) pairs: 9*Cin <= 96 rows
+//                  = 3 fragments instead of 9 fragments of 32 mostly-empty channel rows.
 template <int K, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
-    constexpr int TP = FAST_TP;
-    constexpr int PR = TP / 32;                    // tile rows
-    constexpr int NT = K * K, TH = (NT + 1) / 2;
+struct TCfg {
+    // positions per tile: 64 keeps (accumulators + the register-staged next tile) within 256 registers = 2 waves/SIMD
+    static constexpr int TP = (K == 1) ? 128 : 64;
+};
+
+template <int K, int S, int LW, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(WgradParams p) {
+    constexpr int TP = TCfg<K, S>::TP;
+    constexpr int TW = 1 << LW;
+    constexpr int PR = TP / TW;                    // tile rows
+    constexpr int NT = K * K;
+    constexpr int CB = (MODE == 2) ? 16 : 32;      // input channels staged per workgroup
+    constexpr int NA = (MODE == 0) ? (NT + 1) / 2 : (MODE == 1 ? NT : 3);   // accumulators per wave
     constexpr int PAD = (K == 1) ? 0 : 1;
     constexpr int XR = (PR - 1) * S + K;           // input tile rows
-    constexpr int XC = 31 * S + K;                 // input tile cols
-    constexpr int HALO_R = XC - 32 * S - PAD;      // right halo columns (== 1 for K=3,S=1 and K=4,S=2; 0 for K=1)
+    constexpr int XC = (TW - 1) * S + K;           // input tile cols
+    constexpr int HALO_R = XC - TW * S - PAD;      // right halo columns (== 1 for K=3,S=1 and K=4,S=2; 0 for K=1)
     constexpr int PLANE = XR * XC, PLANEP = PLANE | 1;
-    constexpr int V4 = 8 * S;                      // float4 per interior row
-    constexpr int NXI = 32 * XR * V4;              // interior float4 items
-    constexpr int NXH = (PAD + HALO_R) * 32 * XR;  // halo scalars
-    constexpr int NG = 64 * PR * 8;                // gout float4 items
+    constexpr int V4 = TW * S / 4;                 // float4 per interior row
+    constexpr int GV4 = TW / 4;                    // float4 per gout row
+    constexpr int NXI = CB * XR * V4;              // interior float4 items
+    constexpr int NXH = (PAD + HALO_R) * CB * XR;  // halo scalars
+    constexpr int NG = 64 * PR * GV4;              // gout float4 items
     constexpr int XI_PT = (NXI + 255) / 256, XH_PT = (NXH + 255) / 256, G_PT = NG / 256;
+    constexpr int KS = (MODE == 0) ? TP / 2 : TP / 4;   // k-steps (position pairs) per wave per tile
     static_assert(HALO_R == PAD, "halo is symmetric for the supported kernels");
+    static_assert(NG % 256 == 0 && KS % 2 == 0, "tile shape");
     extern __shared__ float lds[];
-    float* Xl = lds;                    // [32][PLANEP]
-    float* Gl = lds + 32 * PLANEP;      // [64][TP+1]
+    float* Xl = lds;                    // [CB][PLANEP]
+    float* Gl = lds + CB * PLANEP;      // [64][TP+1]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int ofrag = wave & 1, thalf = wave >> 1;
+    const int ofrag = wave & 1, half = wave >> 1;
     const int cb = blockIdx.y * 32, ob = blockIdx.z * 64;
     const int slice = blockIdx.x;
     const int Cin = p.C0 + p.C1;
     const int HWin = p.Hin * p.Win, HWo = p.Hout * p.Wout;
     const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
 
-    f32x16 acc[TH];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int i = 0; i < TH; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -208,12 +225,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
     float xh[XH_PT > 0 ? XH_PT : 1];
     f32x4 gv[G_PT];
 
-    // issue the global loads of one tile into registers
+    // issue the global loads of one tile into registers.  Item order (float4 j, channel, row): the LDS commits of
+    // 32 neighbouring lanes then fall into distinct banks (channel stride PLANEP / TP+1 is odd)
     auto prefetch = [&](int tile) {
         const int n = tile / (p.tiles_x * p.tiles_y);
         const int trem = tile - n * (p.tiles_x * p.tiles_y);
         const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
-        const int oy0 = tyi * PR, ox0 = txi * 32;
+        const int oy0 = tyi * PR, ox0 = txi * TW;
         const float* s0n = p.src0 + (size_t)n * p.C0 * HWin;
         const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HWin : nullptr;
 #pragma unroll
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (e < NXI) {
                 const int j = e % V4, rr = e / V4;
-                const int r = rr % XR, c = rr / XR;
+                const int c = rr % CB, r = rr / CB;
                 int gy = oy0 * S - PAD + r;
                 bool ok = true;
                 if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
@@ -240,9 +258,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
             float v = 0.f;
             if (e < NXH) {
                 const int side = e & 1, rr = e >> 1;          // PAD + HALO_R == 2
-                const int r = rr % XR, c = rr / XR;
+                const int c = rr % CB, r = rr / CB;
                 int gy = oy0 * S - PAD + r;
-                int gx = side == 0 ? ox0 * S - 1 : ox0 * S + 32 * S;
+                int gx = side == 0 ? ox0 * S - 1 : ox0 * S + TW * S;
                 bool ok = true;
                 if (reflect) { gy = reflect_idx(gy, p.Hin); gx = reflect_idx(gx, p.Win); }
                 else ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
@@ -258,8 +276,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
             const int e = tid + i * 256;
-            const int j = e & 7, rr = e >> 3;
-            const int r = rr % PR, o = rr / PR;
+            const int j = e % GV4, rr = e / GV4;
+            const int o = rr & 63, r = rr >> 6;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ob + o < p.Cout)
                 v = *reinterpret_cast<const f32x4*>(gn + (size_t)(ob + o) * HWo + (size_t)(oy0 + r) * p.Wout + ox0 + 4 * j);
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
             const int e = tid + i * 256;
             if (e < NXI) {
                 const int j = e % V4, rr = e / V4;
-                const int r = rr % XR, c = rr / XR;
+                const int c = rr % CB, r = rr / CB;
                 float* d = Xl + c * PLANEP + r * XC + PAD + 4 * j;
                 d[0] = xi[i].x; d[1] = xi[i].y; d[2] = xi[i].z; d[3] = xi[i].w;
             }
@@ -283,27 +301,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
             const int e = tid + i * 256;
             if (e < NXH) {
                 const int side = e & 1, rr = e >> 1;
-                const int r = rr % XR, c = rr / XR;
+                const int c = rr % CB, r = rr / CB;
                 Xl[c * PLANEP + r * XC + (side == 0 ? 0 : XC - 1)] = xh[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
             const int e = tid + i * 256;
-            const int j = e & 7, rr = e >> 3;
-            const int r = rr % PR, o = rr / PR;
-            float* d = Gl + o * (TP + 1) + r * 32 + 4 * j;
+            const int j = e % GV4, rr = e / GV4;
+            const int o = rr & 63, r = rr >> 6;
+            float* d = Gl + o * (TP + 1) + r * TW + 4 * j;
             d[0] = gv[i].x; d[1] = gv[i].y; d[2] = gv[i].z; d[3] = gv[i].w;
         }
     };
 
-    // tap offsets of this wave half
-    int toff[TH];
+    // LDS offset of the A operand of accumulator i for this lane: channel row + tap displacement.  MODE 0/1: the tap
+    // displacement is a compile-time constant folded into the ds_read offset field (one base register).
+    int aoff[MODE == 2 ? NA : 1];
+    if constexpr (MODE == 2) {
 #pragma unroll
-    for (int i = 0; i < TH; ++i) {
-        const int t = 2 * i + thalf;
-        toff[i] = (t / K) * XC + (t % K);
+        for (int i = 0; i < NA; ++i) {
+            const int row = i * 32 + li;                 // (tap, cin) pair; rows past NT*Cin are never written out
+            const int t = row < NT * Cin ? row / Cin : 0, c = row < NT * Cin ? row - t * Cin : 0;
+            aoff[i] = c * PLANEP + (t / K) * XC + (t % K);
+        }
+    } else {
+        aoff[0] = li * PLANEP + (MODE == 0 ? (half / K) * XC + (half % K) : 0);
     }
+    const int kk0 = (MODE == 0) ? 0 : half * KS;
 
     // next valid tile of this slice (padded frames are skipped)
     auto next_tile = [&](int tile) {
@@ -323,44 +348,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradParams p) {
         const int nxt = next_tile(tile + p.nslices);
         if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
         // operand reads software-pipelined one position-pair ahead of the MFMAs (order pinned with sched barriers)
-        auto load_ops = [&](int kk, float (&a)[TH], float& b) {
-            const int q = 2 * kk + lk;
-            const int qy = q >> 5, qx = q & 31;
+        auto load_ops = [&](int kk, float (&a)[NA], float& b) {
+            const int q = 2 * (kk0 + kk) + lk;
+            const int qy = q >> LW, qx = q & (TW - 1);
             b = Gl[(ofrag * 32 + li) * (TP + 1) + q];
-            const int abase = li * PLANEP + (qy * S) * XC + qx * S;
+            const int pos = (qy * S) * XC + qx * S;
 #pragma unroll
-            for (int i = 0; i < TH; ++i) a[i] = (2 * i + thalf < NT) ? Xl[abase + toff[i]] : 0.f;
+            for (int i = 0; i < NA; ++i) {
+                if constexpr (MODE == 2) {
+                    a[i] = Xl[aoff[i] + pos];
+                } else if constexpr (MODE == 1) {
+                    a[i] = Xl[aoff[0] + pos + (i / K) * XC + (i % K)];
+                } else {
+                    // tap 2i + half = tap `half` displaced by 2i taps; K is even, so the row/column split is static
+                    a[i] = Xl[aoff[0] + pos + ((2 * i) / K) * XC + ((2 * i) % K)];
+                }
+            }
         };
-        float a0[TH], a1[TH], b0, b1;
+        auto mfmas = [&](const float (&a)[NA], float b) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (MODE != 0 || 2 * i + half < NT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b, acc[i], 0, 0, 0);
+        };
+        float a0[NA], a1[NA], b0, b1;
         load_ops(0, a0, b0);
 #pragma unroll 2
-        for (int kk = 0; kk < TP / 2; kk += 2) {
+        for (int kk = 0; kk < KS; kk += 2) {
             load_ops(kk + 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TH; ++i)
-                if (2 * i + thalf < NT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0, acc[i], 0, 0, 0);
+            mfmas(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            load_ops(kk + 2 < TP / 2 ? kk + 2 : kk, a0, b0);
+            load_ops(kk + 2 < KS ? kk + 2 : kk, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TH; ++i)
-                if (2 * i + thalf < NT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1, acc[i], 0, 0, 0);
+            mfmas(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         tile = nxt;
     }
 
+    // ---- slab [slice][tap][CinP][CoutB]; position halves are combined through LDS first (fixed order: half 0 + half 1)
+    float* xch = lds;                                  // [ofrag][16][64] floats, reuses the tile area
 #pragma unroll
-    for (int i = 0; i < TH; ++i) {
-        const int t = 2 * i + thalf;
-        if (t < NT) {
-            float* sl = p.slabs + (((size_t)slice * NT + t) * p.CinP + cb) * p.CoutB + ob + ofrag * 32 + li;
+    for (int i = 0; i < NA; ++i) {
+        if constexpr (MODE != 0) {
+            __syncthreads();
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(ofrag * 16 + r) * 64 + lane] = acc[i][r];
+            }
+            __syncthreads();
+            if (half == 1) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += xch[(ofrag * 16 + r) * 64 + lane];
+        }
+        if constexpr (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                sl[(size_t)ci * p.CoutB] = acc[i][r];
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < NT * Cin) {
+                    const int t = row / Cin, c = row - t * Cin;
+                    p.slabs[(((size_t)slice * NT + t) * p.CinP + c) * p.CoutB + ob + ofrag * 32 + li] = acc[i][r];
+                }
+            }
+        } else {
+            const int t = (MODE == 0) ? 2 * i + half : i;
+            if (t < NT) {
+                float* sl = p.slabs + (((size_t)slice * NT + t) * p.CinP + cb) * p.CoutB + ob + ofrag * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    sl[(size_t)ci * p.CoutB] = acc[i][r];
+                }
             }
         }
     }
@@ -403,36 +462,43 @@ void geometry(const c2s_wgrad_desc* d, int TP, int* log2pc, int* tiles_x, int* t
     *tiles_y = cdiv(d->Hout, TP >> l2);
 }
 
-template <int K, int S>
-int launch_wgrad_fast(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
-    constexpr int TP = FAST_TP, PR = TP / 32;
-    constexpr int XR = (PR - 1) * S + K, XC = 31 * S + K;
-    p.log2pc = 5;
-    p.tiles_x = d->Wout / 32;
+template <int K, int S, int LW, int MODE>
+int launch_wgrad_tile(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
+    constexpr int TP = TCfg<K, S>::TP, TW = 1 << LW, PR = TP / TW;
+    constexpr int XR = (PR - 1) * S + K, XC = (TW - 1) * S + K;
+    constexpr int CB = (MODE == 2) ? 16 : 32;
+    p.log2pc = LW;
+    p.tiles_x = d->Wout / TW;
     p.tiles_y = d->Hout / PR;
     p.ntiles = d->N * p.tiles_x * p.tiles_y;
-    const size_t lds = ((size_t)32 * ((XR * XC) | 1) + (size_t)64 * (TP + 1)) * sizeof(float);
+    size_t fl = (size_t)CB * ((XR * XC) | 1) + (size_t)64 * (TP + 1);
+    if (fl < 2 * 16 * 64) fl = 2 * 16 * 64;                       // exchange area of the position halves
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_fast_kernel<K, S>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tile_kernel<K, S, LW, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
-    hipLaunchKernelGGL((conv_wgrad_fast_kernel<K, S>), grid, dim3(256), lds, st, p);
-    C2S_CHECK_LAUNCH("conv_wgrad_fast");
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<K, S, LW, MODE>), grid, dim3(256), fl * sizeof(float), st, p);
+    C2S_CHECK_LAUNCH("conv_wgrad_tile");
     return C2S_OK;
 }
 
 template <int K, int S>
 int launch_wgrad(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
     using C = WCfg<K, S>;
-    {   // fast path: 32-wide aligned tiles
-        constexpr int PR = FAST_TP / 32;
+    {   // tiled path: 32- or 16-wide aligned tiles
+        constexpr int TP = TCfg<K, S>::TP;
+        constexpr int MODE = (K == 4) ? 0 : 1;
         const int pad = (K == 1) ? 0 : 1;
-        if (d->Wout % 32 == 0 && d->Win == d->Wout * S && d->Hin == d->Hout * S && d->Hout % PR == 0 &&
-            d->pad_y == pad && d->pad_x == pad && d->Win % 4 == 0)
-            return launch_wgrad_fast<K, S>(d, p, st);
+        const bool geom = d->Win == d->Wout * S && d->Hin == d->Hout * S && d->pad_y == pad && d->pad_x == pad && d->Win % 4 == 0;
+        if (geom && d->Wout % 32 == 0 && d->Hout % (TP / 32) == 0) {
+            if constexpr (K == 3)
+                if (d->C0 + d->C1 <= 10) return launch_wgrad_tile<K, S, 5, 2>(d, p, st);
+            return launch_wgrad_tile<K, S, 5, MODE>(d, p, st);
+        }
+        if (geom && d->Wout == 16 && d->Hout % (TP / 16) == 0) return launch_wgrad_tile<K, S, 4, MODE>(d, p, st);
     }
     geometry(d, C::TP, &p.log2pc, &p.tiles_x, &p.tiles_y);
     p.ntiles = d->N * p.tiles_x * p.tiles_y;
