@@ -385,7 +385,15 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
     p.tiles_x = cdiv(d->Wout, FC);
     const int tiles = p.tiles_x * cdiv(d->Hout, 8 * FR);
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = d->CoutP % 64 == 0;
+    // 64-channel tiles halve the LDS reads per MFMA, but on small planes (16x16 and below) they leave the grid short of
+    // two workgroups per CU: fall back to 32-channel tiles there
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const bool wide = d->CoutP % 64 == 0 && (long)tiles * d->N * (d->CoutP / 64) >= 2L * cus;
 #define C2S_DISPATCH(K_, S_, A_)                                        \
     if (d->KH == K_ && d->S == S_ && (p.adj != 0) == A_)                \
         return wide ? launch_conv<K_, S_, 2, A_>(p, d->N, tiles, st) : launch_conv<K_, S_, 1, A_>(p, d->N, tiles, st);

@@ -191,6 +191,16 @@ def _igemm(desc: ConvDesc, src0: Tensor, src1: Optional[Tensor], wpk: Tensor, bi
         prof["events"].append((e0, e1))
 
 
+def _xpair_taps(py: int) -> List[int]:
+    """4x4 weight taps of the transposed stride-2 convolution for output-row parity py, ordered [px][ty][tx]."""
+    return [((3 - py) - 2 * ty) * 4 + ((3 - px) - 2 * tx) for px in range(2) for ty in range(2) for tx in range(2)]
+
+
+def _xpair(d: ConvDesc, src: Tensor, wpk: Tensor, bias: Optional[Tensor], out: Tensor, valid: Optional[Tensor]) -> None:
+    check(lib().c2s_conv_xpair(C.byref(d), src.data_ptr(), wpk.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(valid),
+                               _stream()), "conv_xpair")
+
+
 def _wgrad_slices(ctx: Ctx, N: int, Hout: int, Wout: int, S: int, cin: int, cout: int) -> int:
     TP = 64 if S == 2 else 128
     l2 = 5
@@ -278,13 +288,12 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
                     _igemm(dd, g, None, wd, None, gin, valid)
             else:
                 assert K == 4 and S == 2 and pad == 1
-                for py in range(2):
-                    for px in range(2):
-                        taps = [((3 - py) - 2 * ty) * 4 + ((3 - px) - 2 * tx) for ty in range(2) for tx in range(2)]
-                        wd, CP = ctx.pack((wname, "dgrad", si, py, px), W, c_lo * KK, Cout, Cs, 4, KK, Cin * KK, taps)
-                        dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Ho, Wo, Hin, Win, 2, 2, 1, 1 - py, 1 - px,
-                                      _lib.PAD_ZEROS, 2, 2, py, px, accf, radj)
-                        _igemm(dd, g, None, wd, None, gin, valid)
+                assert Hin == 2 * Ho and Win == 2 * Wo
+                for py in range(2):         # one launch per output-row parity, both column parities fused
+                    wd, CP = ctx.pack((wname, "dgrad", si, py), W, c_lo * KK, Cout, Cs, 8, KK, Cin * KK, _xpair_taps(py))
+                    dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Ho, Wo, Hin, Win, 2, 2, 1, 1 - py, 0, _lib.PAD_ZEROS,
+                                  2, 2, py, 0, accf, radj)
+                    _xpair(dd, g, wd, None, gin, valid)
             if existing is None:
                 tape.grads[src.data_ptr()] = gin
             c_lo += Cs
@@ -301,12 +310,9 @@ def conv_transpose2d(ctx: Ctx, x: Tensor, wname: str, bname: str) -> Tensor:
     out = torch.empty(N, Cout, 2 * H, 2 * Wd, device=x.device, dtype=torch.float32)
     bias = ctx.p[bname]
     for py in range(2):
-        for px in range(2):
-            taps = [((3 - py) - 2 * ty) * 4 + ((3 - px) - 2 * tx) for ty in range(2) for tx in range(2)]
-            wpk, CP = ctx.pack((wname, "fwd", py, px), Wt, 0, Cin, Cout, 4, 16, Cout * 16, taps)
-            d = ConvDesc(N, Cin, 0, H, Wd, Cout, CP, H, Wd, 2 * H, 2 * Wd, 2, 2, 1, 1 - py, 1 - px, _lib.PAD_ZEROS,
-                         2, 2, py, px, 0)
-            _igemm(d, x, None, wpk, bias, out, None)
+        wpk, CP = ctx.pack((wname, "fwd", py), Wt, 0, Cin, Cout, 8, 16, Cout * 16, _xpair_taps(py))
+        d = ConvDesc(N, Cin, 0, H, Wd, Cout, CP, H, Wd, 2 * H, 2 * Wd, 2, 2, 1, 1 - py, 0, _lib.PAD_ZEROS, 2, 2, py, 0, 0)
+        _xpair(d, x, wpk, bias, out, None)
     if ctx.tape is None:
         return out
     tape = ctx.tape

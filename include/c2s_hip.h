@@ -83,6 +83,20 @@ int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const float* src1,
                    const float* bias, float* out, const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Transposed 4x4 stride-2 pad-1 convolution, one output-row parity per launch, both column parities fused:
+ *   out[n, o, 2i+py, 2j+px] (+)= bias[o] + sum_{c,ty,tx} in[n, c, i-(1-py)+ty, j-(1-px)+tx] * wpk[px][ty*2+tx][c][o]
+ * with py = 1 - d->pad_y.  Descriptor: KH = KW = 2, S = 1, pad_mode = ZEROS, C1 = 0, Hout = Hin, Wout = Win,
+ * OutH = 2*Hout, OutW = 2*Wout, osy = osx = 2, ooy = py (pad_x / oox unused); wpk = c2s_pack_weights with the 8 taps
+ * (px-major).  Each lane stores the two column parities as one float2 (full-line stores; the single-parity
+ * launches of c2s_conv_igemm wrote every other float).  reflect_adjoint = 1: data gradient of a reflect-padded
+ * 4x4-stride-2 convolution (the halo gradient is folded back inside the kernel).
+ * Replaces: nn.ConvTranspose2d(4,2,1) forward (conv.py:384-390) and the convolution_backward-input of the strided
+ * down convolutions (conv.py:263-271): two launches (py = 0, 1) each.
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_conv_xpair(const c2s_conv_desc* d, const float* src, const float* wpk, const float* bias, float* out,
+                   const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Opt-in split-precision variant of the 3x3 stride-1 pad-1 convolution (forward and data gradient, same
  * descriptor as c2s_conv_igemm): every fp32 operand is split into two bf16 halves (hi + lo, 16 significant bits)
  * and each product evaluated with three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi) accumulating in fp32
