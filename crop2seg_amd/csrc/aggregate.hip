@@ -99,33 +99,37 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const float* __restrict__ 
 }
 
 // adjoint of the bilinear upsample: one thread per low-resolution attention cell (gather, deterministic)
+// Adjoint of the bilinear upsampling of the attention masks: gattn[plane][i][j] += sum_{Y,X} wy(Y,i) wx(X,j) gup[plane][Y][X].
+// One workgroup per (plane, low-resolution row i), separable: thread X first folds the <= 3*H/h contributing rows
+// of column X (coalesced row reads), then thread j folds the <= 3*W/w contributing columns out of LDS.
 __global__ __launch_bounds__(256) void agg_upsample_adjoint_kernel(const float* __restrict__ gup, float* __restrict__ gattn,
                                                                    c2s_agg_desc d) {
-    const long total = (long)d.n_head * d.B * d.T * d.h * d.w;
-    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int j = (int)(e % d.w);
-    long r = e / d.w;
-    const int i = (int)(r % d.h);
-    const long plane = r / d.h;
+    extern __shared__ float colsum[];               // [W]
+    const long plane = blockIdx.x / d.h;
+    const int i = blockIdx.x % d.h;
     const int sy = d.H / d.h, sx = d.W / d.w;
     const int y0 = max(0, (i - 1) * sy), y1 = min(d.H, (i + 2) * sy);
-    const int x0 = max(0, (j - 1) * sx), x1 = min(d.W, (j + 2) * sx);
     const float* gp = gup + (size_t)plane * d.H * d.W;
-    float acc = 0.f;
-    for (int Y = y0; Y < y1; ++Y) {
-        const Taps ty = taps_for(Y, d.h, d.H);
-        const float wy = (ty.i0 == i ? ty.w0 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
-        if (wy == 0.f) continue;
-        float row = 0.f;
+    for (int X = threadIdx.x; X < d.W; X += blockDim.x) {
+        float acc = 0.f;
+        for (int Y = y0; Y < y1; ++Y) {
+            const Taps ty = taps_for(Y, d.h, d.H);
+            const float wy = (ty.i0 == i ? ty.w0 : 0.f) + (ty.i1 == i ? ty.w1 : 0.f);
+            acc += wy * gp[(size_t)Y * d.W + X];
+        }
+        colsum[X] = acc;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < d.w; j += blockDim.x) {
+        const int x0 = max(0, (j - 1) * sx), x1 = min(d.W, (j + 2) * sx);
+        float acc = 0.f;
         for (int X = x0; X < x1; ++X) {
             const Taps tx = taps_for(X, d.w, d.W);
             const float wx = (tx.i0 == j ? tx.w0 : 0.f) + (tx.i1 == j ? tx.w1 : 0.f);
-            row += wx * gp[(size_t)Y * d.W + X];
+            acc += wx * colsum[X];
         }
-        acc += wy * row;
+        gattn[((size_t)plane * d.h + i) * d.w + j] += acc;
     }
-    gattn[e] += acc;
 }
 
 int check(const c2s_agg_desc* d) {
@@ -180,8 +184,10 @@ extern "C" int c2s_temporal_aggregate_bwd(const c2s_agg_desc* d, const float* x,
         default: hipLaunchKernelGGL(agg_bwd_kernel<16>, grid, block, 0, st, x, attn, valid, gout, gx, gx_accumulate, workspace, *d); break;
     }
     C2S_CHECK_LAUNCH("aggregate_bwd");
-    const long cells = (long)d->n_head * d->B * d->T * d->h * d->w;
-    hipLaunchKernelGGL(agg_upsample_adjoint_kernel, dim3(cdiv(cells, 256)), dim3(256), 0, st, workspace, gattn, *d);
+    const long rows = (long)d->n_head * d->B * d->T * d->h;
+    const int threads = d->W >= 256 ? 256 : (d->W > 64 ? 128 : 64);
+    hipLaunchKernelGGL(agg_upsample_adjoint_kernel, dim3(rows), dim3(threads), (size_t)d->W * sizeof(float), st, workspace,
+                       gattn, *d);
     C2S_CHECK_LAUNCH("aggregate_upsample_adjoint");
     return C2S_OK;
 }

@@ -221,25 +221,42 @@ __global__ __launch_bounds__(256) void norm_bwd_sums_kernel(const float* __restr
     if (lane == 0) { part[item * 3] = s1; part[item * 3 + 1] = s2; part[item * 3 + 2] = sx; }
 }
 
-// rows[row] = sums over segments (double accumulate)  -> rowsum[row][3]
-__global__ void norm_bwd_rowsum_kernel(const float* __restrict__ part, float* __restrict__ rowsum, long rows, int segs) {
-    const long row = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    double a = 0, b = 0, c = 0;
+// One launch for the two small reductions between the sums pass and the apply pass (wave per block):
+//   blocks [0, ngroups):      coefficients k1,k2,k3 per row of the group ( dx = k1*g' + k2*(x-mean) + k3 )
+//   blocks [ngroups, +C):     dgamma, dbeta of one channel (sum over frames)
+// Both read the per-(row, segment) partials directly; sums run in double in a fixed order.
+__device__ __forceinline__ void row_sums(const float* __restrict__ part, long row, int segs, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
     for (int s = 0; s < segs; ++s) {
-        a += part[(row * segs + s) * 3];
-        b += part[(row * segs + s) * 3 + 1];
-        c += part[(row * segs + s) * 3 + 2];
+        s1 += part[(row * segs + s) * 3];
+        s2 += part[(row * segs + s) * 3 + 1];
     }
-    rowsum[row * 3] = (float)a; rowsum[row * 3 + 1] = (float)b; rowsum[row * 3 + 2] = (float)c;
 }
 
-// one wave per group: coefficients k1,k2,k3 per row ( dx = k1*g' + k2*(x-mean) + k3 )
-__global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restrict__ rowsum, const float* __restrict__ gamma,
-                                                           const float* __restrict__ gstats, float* __restrict__ rowk,
-                                                           const int* __restrict__ valid, c2s_norm_desc d) {
-    const int grp = blockIdx.x;
+__global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                             const float* __restrict__ gstats, float* __restrict__ rowk,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             const int* __restrict__ valid, c2s_norm_desc d, int segs,
+                                                             int ngroups) {
     const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= ngroups) {
+        const int c = blockIdx.x - ngroups;
+        double dg = 0, db = 0;
+        for (int n = lane; n < d.N; n += 64) {
+            if (valid != nullptr && valid[n] == 0) continue;
+            double s1, s2;
+            row_sums(part, (long)n * d.C + c, segs, s1, s2);
+            dg += (double)(float)s2;
+            db += (double)(float)s1;
+        }
+        for (int o = 32; o > 0; o >>= 1) { dg += __shfl_xor(dg, o, 64); db += __shfl_xor(db, o, 64); }
+        if (lane == 0) {
+            if (dgamma != nullptr) dgamma[c] = (float)dg;
+            if (dbeta != nullptr) dbeta[c] = (float)db;
+        }
+        return;
+    }
+    const int grp = blockIdx.x;
     const bool batch = d.kind == C2S_NORM_BATCH;
     const int cpg = batch ? 1 : d.C / d.groups;
     const int n_rows = batch ? d.N : cpg;
@@ -250,8 +267,10 @@ __global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restri
         const int n = (int)(row / d.C);
         if (valid != nullptr && valid[n] == 0) continue;
         const float gm = gamma[row % d.C];
-        A += (double)gm * rowsum[row * 3];
-        Bv += (double)gm * rowsum[row * 3 + 1];
+        double s1, s2;
+        row_sums(part, row, segs, s1, s2);
+        A += (double)gm * (double)(float)s1;
+        Bv += (double)gm * (double)(float)s2;
         cnt += d.HW;
     }
     for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o, 64); Bv += __shfl_xor(Bv, o, 64); cnt += __shfl_xor(cnt, o, 64); }
@@ -269,25 +288,6 @@ __global__ __launch_bounds__(64) void norm_bwd_coef_kernel(const float* __restri
             }
         }
         rowk[row * 3] = k1; rowk[row * 3 + 1] = k2; rowk[row * 3 + 2] = k3;
-    }
-}
-
-// per channel: dgamma, dbeta (sum over frames); one wave per channel, lanes over frames
-__global__ __launch_bounds__(64) void norm_bwd_param_kernel(const float* __restrict__ rowsum, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, const int* __restrict__ valid,
-                                                            int N, int C) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    double dg = 0, db = 0;
-    for (int n = lane; n < N; n += 64) {
-        if (valid != nullptr && valid[n] == 0) continue;
-        const long row = (long)n * C + c;
-        dg += rowsum[row * 3 + 1];
-        db += rowsum[row * 3];
-    }
-    for (int o = 32; o > 0; o >>= 1) { dg += __shfl_xor(dg, o, 64); db += __shfl_xor(db, o, 64); }
-    if (lane == 0) {
-        if (dgamma != nullptr) dgamma[c] = (float)dg;
-        if (dbeta != nullptr) dbeta[c] = (float)db;
     }
 }
 
@@ -426,14 +426,10 @@ extern "C" int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float*
     hipLaunchKernelGGL(norm_bwd_sums_kernel, dim3(cdiv(nitems, 4)), dim3(256), 0, st, x, g, row_ab, group_stats, part,
                        valid, *d, segs, nitems, relu);
     C2S_CHECK_LAUNCH("norm_bwd_sums");
-    hipLaunchKernelGGL(norm_bwd_rowsum_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, part, rowsum, rows, segs);
-    C2S_CHECK_LAUNCH("norm_bwd_rowsum");
     const int ngroups = d->kind == C2S_NORM_BATCH ? d->C : d->N * d->groups;
-    hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3(ngroups), dim3(64), 0, st, rowsum, gamma, group_stats, rowk, valid, *d);
-    C2S_CHECK_LAUNCH("norm_bwd_coef");
-    hipLaunchKernelGGL(norm_bwd_param_kernel, dim3(d->C), dim3(64), 0, st, rowsum, dgamma, dbeta, valid, d->N,
-                       d->C);
-    C2S_CHECK_LAUNCH("norm_bwd_param");
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(ngroups + d->C), dim3(64), 0, st, part, gamma, group_stats, rowk, dgamma,
+                       dbeta, valid, *d, segs, ngroups);
+    C2S_CHECK_LAUNCH("norm_bwd_reduce");
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(cdiv(nitems, 4)), dim3(256), 0, st, x, g, row_ab, rowk, gx, part, valid,
                        d->C, d->HW, segs, nitems, relu);
     C2S_CHECK_LAUNCH("norm_bwd_apply");
