@@ -145,6 +145,26 @@ def _pack_bf16x3(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, co
     return whi, wlo, coutP
 
 
+def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, cout: int, so: int, sc: int,
+                   taps: Sequence[int]) -> Tuple[Tensor, int]:
+    """U = G g Gt of every 3x3 filter, [16][cin][coutP] (cached per forward)."""
+    hit = ctx._packed.get(key)
+    coutP = (cout + 63) // 64 * 64
+    if hit is not None:
+        return hit, coutP
+    upk = torch.empty(16 * cin * coutP, device=ctx.device, dtype=torch.float32)
+    check(lib().c2s_pack_weights_winograd(src.data_ptr() + 4 * src_off, upk.data_ptr(), cin, cout, coutP, so, sc,
+                                          _tap_array(taps), _stream()), "pack_weights_winograd")
+    ctx._packed[key] = upk
+    return upk, coutP
+
+
+def _use_winograd(K: int, S: int, pad: int, chans: Sequence[int], cout: int, H: int, W: int) -> bool:
+    """Winograd F(2x2,3x3) pays off where the 16 transform-domain GEMMs are deep and wide enough."""
+    return (WINOGRAD and CONV_MODE == "f32" and K == 3 and S == 1 and pad == 1 and sum(chans) >= 32 and cout >= 64
+            and H % 2 == 0 and W % 2 == 0 and W >= 8 and (len(chans) == 1 or chans[0] % 8 == 0))
+
+
 def _use_bf16x3(K: int, S: int, pad: int, chans: Sequence[int]) -> bool:
     return CONV_MODE == "bf16x3" and K == 3 and S == 1 and pad == 1 and all(c % 8 == 0 for c in chans)
 
@@ -171,6 +191,8 @@ import os as _os
 
 CONV_MODE = _os.environ.get("C2S_CONV_MODE", "f32")
 assert CONV_MODE in ("f32", "bf16x3"), CONV_MODE
+# fp32 Winograd F(2x2,3x3) for the wide 3x3 layers (forward + data gradient); C2S_WINOGRAD=0 keeps the direct kernel.
+WINOGRAD = _os.environ.get("C2S_WINOGRAD", "1") != "0"
 
 # bench.py sets PROFILE = {"match": {field: value}, "events": []}: launches whose descriptor matches are bracketed
 # with HIP events on the launch stream (the stream the kernel runs on) for the live roofline measurement.
@@ -186,6 +208,20 @@ def _igemm(desc: ConvDesc, src0: Tensor, src1: Optional[Tensor], wpk: Tensor, bi
         e0.record()
     check(lib().c2s_conv_igemm(C.byref(desc), src0.data_ptr(), _ptr(src1), wpk.data_ptr(), _ptr(bias), out.data_ptr(),
                                _ptr(valid), _stream()), "conv_igemm")
+    if timed:
+        e1.record()
+        prof["events"].append((e0, e1))
+
+
+def _winograd(desc: ConvDesc, src0: Tensor, src1: Optional[Tensor], upk: Tensor, bias: Optional[Tensor], out: Tensor,
+              valid: Optional[Tensor]) -> None:
+    prof = PROFILE
+    timed = prof is not None and all(getattr(desc, k) == v for k, v in prof["match"].items())
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().c2s_conv3x3_winograd(C.byref(desc), src0.data_ptr(), _ptr(src1), upk.data_ptr(), _ptr(bias),
+                                     out.data_ptr(), _ptr(valid), _stream()), "conv3x3_winograd")
     if timed:
         e1.record()
         prof["events"].append((e0, e1))
@@ -243,7 +279,11 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     Wo = (Win + 2 * pad - K) // S + 1
     KK = K * K
     out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
-    if _use_bf16x3(K, S, pad, [C0, C1]):
+    if _use_winograd(K, S, pad, [C0, C1] if C1 else [C0], Cout, Hin, Win):
+        upk, CoutP = _pack_winograd(ctx, (wname, "fwd", "wino"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)))
+        d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
+        _winograd(d, s0, s1, upk, ctx.p[bname] if bname else None, out, valid)
+    elif _use_bf16x3(K, S, pad, [C0, C1]):
         whi, wlo, CoutP = _pack_bf16x3(ctx, (wname, "fwd", "bx"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)))
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
         check(lib().c2s_conv3x3_bf16x3(C.byref(d), s0.data_ptr(), _ptr(s1), whi.data_ptr(), wlo.data_ptr(),
@@ -275,7 +315,12 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             radj = 1 if (pad_mode == _lib.PAD_REFLECT and pad > 0) else 0   # reflection adjoint folded into the kernel
             if S == 1:
                 taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
-                if _use_bf16x3(K, S, pad, [Cout]):
+                if _use_winograd(K, S, pad, [Cout], Cs, Hin, Win):
+                    upk, CP = _pack_winograd(ctx, (wname, "dgrad", "wino", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps)
+                    dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
+                                  accf, radj)
+                    _winograd(dd, g, None, upk, None, gin, valid)
+                elif _use_bf16x3(K, S, pad, [Cout]):
                     whi, wlo, CP = _pack_bf16x3(ctx, (wname, "dgrad", "bx", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps)
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
                                   accf, radj)

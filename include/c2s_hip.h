@@ -97,6 +97,21 @@ int c2s_conv_xpair(const c2s_conv_desc* d, const float* src, const float* wpk, c
                    const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3x3 stride-1 pad-1 convolution as Winograd F(2x2,3x3) on the f32 MFMA (2.25x fewer multiplies than
+ * c2s_conv_igemm; all arithmetic fp32, error a few 1e-7 of sum|a*b|).  Same descriptor as c2s_conv_igemm with
+ * KH = KW = 3, S = 1, pad = 1, dense same-size output, even planes with W >= 8, CoutP a multiple of 64;
+ * upk = c2s_pack_weights_winograd ([16][Cin][CoutP] = G g Gt per filter; tap table as for c2s_pack_weights, so the
+ * flipped table gives the data-gradient filters).  reflect_adjoint = 1 (zero-padded launch): the adjoint of the
+ * reflection is applied to the raw patches of the border blocks inside the kernel.
+ * Replaces: nn.Conv2d 3x3 forward (conv.py:70-80,378-382) and its convolution_backward-input for layers with
+ * >= 32 input and >= 64 output channels (the engine keeps c2s_conv_igemm for the rest).
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_pack_weights_winograd(const float* src, float* upk, int cin, int cout, int coutP, long stride_o, long stride_c,
+                              const int* host_tap_off, void* stream);
+int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
+                         const float* bias, float* out, const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Opt-in split-precision variant of the 3x3 stride-1 pad-1 convolution (forward and data gradient, same
  * descriptor as c2s_conv_igemm): every fp32 operand is split into two bf16 halves (hi + lo, 16 significant bits)
  * and each product evaluated with three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi) accumulating in fp32
