@@ -20,6 +20,7 @@
 // Reference call sites replaced: nn.Conv2d 3x3 (src/backbones/conv.py:70-80,378-382) and its
 // convolution_backward-input, including reflection_pad2d_backward (conv.py:72-79).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,142 +33,168 @@ struct WinoParams {
     const int* valid;
     int C0, C1, H, W, Cout, CoutP;
     int pad_mode, accumulate;
-    int log2bc, tiles_x;
+    int N, tiles, tiles_x, nchunks;
 };
 
 constexpr int WN_CK = 8;
-constexpr int wn_plane(int l2) { return (2 * (32 >> l2) + 2) * (2 * (1 << l2) + 2); }
-constexpr int wn_max(int a, int b) { return a > b ? a : b; }
-constexpr int WN_MAXPLANE = wn_max(wn_max(wn_plane(2), wn_plane(3)), wn_plane(4));
-constexpr int WN_MAXE = (WN_CK * WN_MAXPLANE + 255) / 256;
 constexpr int WN_USLAB = 16 * WN_CK * 64;          // floats of one U chunk
-constexpr int WN_EXCH = 4 * 2 * 32 * 64;           // floats of the epilogue exchange [xi][x][m*16+r][lane]
+constexpr int WN_EXCH = 4 * 2 * 16 * 64;           // floats of the epilogue exchange [xi][x][r][lane] (one 32-channel half)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool ADJ>
+#ifdef C2S_WN_STAMP
+// diagnostic build only: per-workgroup cycles spent in each phase, summed over the tiles the workgroup processed
+// (slot k accumulates the time between stamp k-1 and stamp k; slot 0 counts tiles)
+__device__ unsigned long long wn_stamps[8192 * 8];
+#define WN_STAMP_DECL unsigned long long wn_t_ = __builtin_amdgcn_s_memtime(), wn_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WN_STAMP(k)                                                     \
+    do {                                                                \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();  \
+        wn_acc_[k] += (k) == 0 ? 1 : now__ - wn_t_;                     \
+        wn_t_ = now__;                                                  \
+    } while (0)
+#define WN_STAMP_FLUSH                                                                                    \
+    do {                                                                                                  \
+        const int wg__ = blockIdx.y * gridDim.x + blockIdx.x;                                             \
+        if (threadIdx.x == 0 && wg__ < 8192)                                                              \
+            for (int k__ = 0; k__ < 8; ++k__) wn_stamps[wg__ * 8 + k__] = wn_acc_[k__];                   \
+    } while (0)
+#else
+#define WN_STAMP_DECL
+#define WN_STAMP(k)
+#define WN_STAMP_FLUSH
+#endif
+
+// Persistent workgroups: each walks tiles t = blockIdx.x, +gridDim.x, ... of (frame, tile) order; the requests for the
+// next tile's first chunk are issued before the epilogue of the current tile, so their latency hides behind the
+// exchange and the stores instead of sitting in front of the next K loop.
+// Staging: the U chunk goes global -> LDS directly (global_load_lds_dwordx4: its LDS image [xn][c][o] is lane-linear),
+// which keeps 32 staging registers free next to the 128 accumulators; the gathered raw tile is register-staged.
+#define C2S_AS1 __attribute__((address_space(1)))
+#define C2S_AS3 __attribute__((address_space(3)))
+
+template <int LOG2BC, bool ADJ>
 __global__ __launch_bounds__(256, 2) void conv_winograd_kernel(WinoParams p) {
-    constexpr int CK = WN_CK, MAXE = WN_MAXE;
+    constexpr int CK = WN_CK;
+    constexpr int BC = 1 << LOG2BC, BR = 32 >> LOG2BC;
+    constexpr int RR = 2 * BR + 2, RC = 2 * BC + 2;
+    constexpr int plane = RR * RC;                // even
+    constexpr int total = CK * plane;
+    constexpr int MAXE = (total + 255) / 256;
     constexpr int NWV = WN_USLAB / 4;             // float4 items of the U chunk
     constexpr int WPT = NWV / 256;
     constexpr int NS = CK / 2;                    // k-steps (channel pairs) per chunk
+    constexpr int xsz = total;
+    constexpr int BUF = xsz + WN_USLAB;
+    static_assert(CK == 8 && WN_EXCH <= BUF, "chunk decomposition / exchange area");
     extern __shared__ float lds[];
-
-    const int n = blockIdx.z;
-    if (p.valid != nullptr && p.valid[n] == 0) return;
-
-    const int BC = 1 << p.log2bc, BR = 32 >> p.log2bc;
-    const int RR = 2 * BR + 2, RC = 2 * BC + 2;
-    const int plane = RR * RC;                    // even
-    const int xsz = CK * plane;
     float* Xl = lds;                              // [2][ [CK][plane] | [16][CK][64] ]
     float* Wl = lds + xsz;
-    const int BUF = xsz + WN_USLAB;
 
-    const int tyi = blockIdx.x / p.tiles_x, txi = blockIdx.x % p.tiles_x;
-    const int oy0 = tyi * 2 * BR, ox0 = txi * 2 * BC;
     const int co0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
     const int Cin = p.C0 + p.C1;
     const int HW = p.H * p.W;
-
-    int goff[MAXE];
-    const int total = CK * plane;
-#pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-        const int e = tid + i * 256;
-        int off = -1;
-        if (e < total) {
-            const int c = e / plane;
-            const int rem = e - c * plane;
-            const int r = rem / RC;
-            const int cc = rem - r * RC;
-            int gy = oy0 - 1 + r, gx = ox0 - 1 + cc;
-            bool ok;
-            if (p.pad_mode == C2S_PAD_REFLECT) {
-                ok = gy >= -1 && gy <= p.H && gx >= -1 && gx <= p.W;
-                gy = reflect_idx(gy, p.H);
-                gx = reflect_idx(gx, p.W);
-            } else {
-                ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            }
-            if (ok) off = (c * HW + gy * p.W + gx) * 4;
-        }
-        goff[i] = off;
-    }
-
     const int lane = tid & 63, xi = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int by = li >> p.log2bc, bx = li & (BC - 1);
+    const int by = li >> LOG2BC, bx = li & (BC - 1);
     // patch rows combined by this wave: t = ca * d[ra] + cb * d[rb]   (rows of Bt)
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
-    float ca = 1.f, cb = xi == 1 ? 1.f : -1.f, e0 = 1.f, e3 = 1.f;
-    if constexpr (ADJ) {
-        const int gby = (oy0 >> 1) + by, gbx = (ox0 >> 1) + bx;      // global block coordinates
-        const bool top = gby == 0, bottom = gby == (p.H >> 1) - 1;
-        const bool left = gbx == 0, right = gbx == (p.W >> 1) - 1;
-        if (xi == 0 && bottom) cb = 0.f;        // d0 += d2  ->  (d0 + d2) - d2
-        if (xi == 3 && top) ca = 0.f;           // d3 += d1  ->  d1 - (d3 + d1)
-        if (right) e0 = 0.f;                    // col0 += col2
-        if (left) e3 = 0.f;                     // col3 += col1
-    }
     const int boffa = lk * plane + (2 * by + ra) * RC + 2 * bx;
     const int boffb = lk * plane + (2 * by + rb) * RC + 2 * bx;
     const int aoff = (xi * 4 * CK + lk) * 64 + li;
+    const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
 
-    f32x16 acc[4][2];
+    // staging element of this thread packed as (channel << 20 | tile row << 10 | tile col); -1 = none
+    int epk[MAXE];
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[v][m][r] = 0.f;
+    for (int i = 0; i < MAXE; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / plane, rem = e % plane;     // compile-time divisors
+        epk[i] = e < total ? ((c << 20) | ((rem / RC) << 10) | (rem % RC)) : -1;
+    }
 
-    const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
-    const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HW * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(s1n != nullptr ? s1n : s0n), 0,
-                                                                         p.C1 * HW * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.upk, 0, 16 * Cin * p.CoutP * 4, 0x00020000);
+    // ---- per-tile state
+    int goff[MAXE];
+    int n = 0, oy0 = 0, ox0 = 0;
+    float ca = 1.f, cb = xi == 1 ? 1.f : -1.f, e0 = 1.f, e3 = 1.f;
+    __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src0, 0, 0, 0x00020000), r1 = r0;
+    const int ntotal = p.N * p.tiles;
+
+    auto next_valid = [&](int t) {
+        while (t < ntotal && p.valid != nullptr && p.valid[t / p.tiles] == 0) t += gridDim.x;
+        return t;
+    };
+    auto begin_tile = [&](int t) {
+        n = t / p.tiles;
+        const int tt = t - n * p.tiles;
+        const int tyi = tt / p.tiles_x, txi = tt - tyi * p.tiles_x;
+        oy0 = tyi * 2 * BR; ox0 = txi * 2 * BC;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int pk = epk[i];
+            int gy = oy0 - 1 + ((pk >> 10) & 1023), gx = ox0 - 1 + (pk & 1023);
+            bool ok = pk >= 0;
+            if (reflect) {
+                ok = ok && gy <= p.H && gx <= p.W;       // gy, gx >= -1 by construction
+                gy = reflect_idx(gy, p.H);
+                gx = reflect_idx(gx, p.W);
+            } else {
+                ok = ok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            }
+            goff[i] = ok ? (((pk >> 20) * HW + gy * p.W + gx) * 4) : -1;
+        }
+        if constexpr (ADJ) {
+            const int gby = (oy0 >> 1) + by, gbx = (ox0 >> 1) + bx;      // global block coordinates
+            const bool top = gby == 0, bottom = gby == (p.H >> 1) - 1;
+            const bool left = gbx == 0, right = gbx == (p.W >> 1) - 1;
+            ca = (xi == 3 && top) ? 0.f : 1.f;                      // d3 += d1  ->  d1 - (d3 + d1)
+            cb = xi == 1 ? 1.f : ((xi == 0 && bottom) ? 0.f : -1.f); // d0 += d2  ->  (d0 + d2) - d2
+            e0 = right ? 0.f : 1.f;                                 // col0 += col2
+            e3 = left ? 0.f : 1.f;                                  // col3 += col1
+        }
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
+        const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
+        r0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HW * 4, 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(s1n != nullptr ? s1n : s0n), 0, p.C1 * HW * 4, 0x00020000);
+    };
 
     float xr[MAXE];
-    f32x4 wr[WPT];
-    auto prefetch = [&](int cb_) {
+    // raw tile of chunk cb_: global -> registers (out-of-range offsets return 0: padding, channels past Cin);
+    // one request per call so that the K loop can place them between MFMAs
+    auto prefetch_raw_piece = [&](int cb_, int i) {
         const bool first = cb_ < p.C0;
         const int chan0 = (first ? cb_ : cb_ - p.C0) * HW * 4;
-        if (first) {
-#pragma unroll
-            for (int i = 0; i < MAXE; ++i)
-                xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, goff[i] >= 0 ? goff[i] + chan0 : -1, 0, 0));
-        } else {
-#pragma unroll
-            for (int i = 0; i < MAXE; ++i)
-                xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, goff[i] >= 0 ? goff[i] + chan0 : -1, 0, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * 256;             // float4 item: [xn 16][c CK][o4 16]
-            const int o4 = e & 15, c = (e >> 4) & (CK - 1), xn = e >> 7;
-            static_assert(CK == 8, "item decomposition assumes 8 channels per chunk");
-            const bool ok = cb_ + c < Cin;
-            const int off = ok ? (((xn * Cin + cb_ + c) * p.CoutP + co0 + o4 * 4) * 4) : -1;
-            wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
-        }
+        const int off = goff[i] >= 0 ? goff[i] + chan0 : -1;
+        xr[i] = __builtin_bit_cast(float, first ? __builtin_amdgcn_raw_buffer_load_b32(r0, off, 0, 0)
+                                                : __builtin_amdgcn_raw_buffer_load_b32(r1, off, 0, 0));
     };
-    auto commit = [&](int buf) {
+    auto prefetch_raw = [&](int cb_) {
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) prefetch_raw_piece(cb_, i);
+    };
+    auto commit_raw = [&](int buf) {
         float* Xd = Xl + buf * BUF;
-        float* Wd = Wl + buf * BUF;
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int e = tid + i * 256;
             if (e < total) Xd[e] = xr[i];
         }
+    };
+    // U chunk cb_: global -> LDS.  The packed layout [cout block][chunk][xn 16][c 8][o 64] makes a chunk one contiguous
+    // 32 KB run that is copied verbatim (float4 item e lands at byte 16*e of the slab: lane-linear, as LDS-DMA needs),
+    // and spreads consecutive chunks over all L2 channels (a [xn][cin][cout] layout put the 16 pieces of a chunk
+    // 16 KB apart = on 4 of the 16 channels of the XCD's L2).
+    const float* ublock = p.upk + (size_t)blockIdx.y * p.nchunks * WN_USLAB + tid * 4;
+    auto stage_u_piece = [&](int cb_, int buf, int i) {
+        float* Wd = Wl + buf * BUF + tid * 4;
+        const float* g = ublock + (size_t)(cb_ / CK) * WN_USLAB;
+        __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 1024), (C2S_AS3 void*)(Wd + i * 1024), 16, 0, 0);
+    };
+    auto stage_u = [&](int cb_, int buf) {
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * 256;
-            *reinterpret_cast<f32x4*>(Wd + (size_t)e * 4) = wr[i];
-        }
+        for (int i = 0; i < WPT; ++i) stage_u_piece(cb_, buf, i);
     };
 
     // raw patch rows + U operands of k-step s (channels 2s, 2s+1)
@@ -204,91 +231,159 @@ __global__ __launch_bounds__(256, 2) void conv_winograd_kernel(WinoParams p) {
         V[2] = t2 - t1;
     };
 
-    constexpr int COMMIT_AT = NS / 2;
-    prefetch(0);
-    commit(0);
-    if (CK < Cin) prefetch(CK);
-    __syncthreads();
+    int t = next_valid(blockIdx.x);
+    if (t >= ntotal) return;
+    WN_STAMP_DECL
+    begin_tile(t);
+    WN_STAMP(1);
     int cur = 0;
-    for (int cb_ = 0; cb_ < Cin; cb_ += CK, cur ^= 1) {
-        const float* Xc = Xl + cur * BUF;
-        const float* Wc = Wl + cur * BUF;
-        f32x2 d[2][4];
-        float a[2][4][2];
-        load_ops(Xc, Wc, 0, d[0], a[0]);
+    stage_u(0, cur);
+    prefetch_raw(0);
+    while (true) {
+        f32x16 acc[4][2];
 #pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
-            float V[4];
-            transform(d[s_ & 1], V);
-            if (s_ + 1 < NS) load_ops(Xc, Wc, s_ + 1, d[(s_ + 1) & 1], a[(s_ + 1) & 1]);
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[v][m][r] = 0.f;
+        WN_STAMP(0);
+        commit_raw(cur);
+        __syncthreads();                              // (also drains the U chunk's LDS-DMA: vmcnt(0))
+        WN_STAMP(2);
+        for (int cb_ = 0; cb_ < Cin; cb_ += CK, cur ^= 1) {
+            const float* Xc = Xl + cur * BUF;
+            const float* Wc = Wl + cur * BUF;
+            const bool nextc = cb_ + CK < Cin;
+            f32x2 d[2][4];
+            float a[2][4][2];
+            load_ops(Xc, Wc, 0, d[0], a[0]);
             __builtin_amdgcn_sched_barrier(0);
+            static_assert(WPT + MAXE <= 2 * 8, "the next chunk's requests are spread over the MFMAs of two k-steps");
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    acc[v][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][v][m], V[v], acc[v][m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s_ == COMMIT_AT && cb_ + CK < Cin) {
-                commit(cur ^ 1);
-                if (cb_ + 2 * CK < Cin) prefetch(cb_ + 2 * CK);
+            for (int s_ = 0; s_ < NS; ++s_) {
+                float V[4];
+                transform(d[s_ & 1], V);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int v = j >> 1, m = j & 1;
+                    acc[v][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][v][m], V[v], acc[v][m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // behind the MFMA just issued (each runs 64 cycles): the LDS reads of the next step (j == 0) and one
+                    // request of the next chunk per MFMA -- an LDS-DMA piece costs ~60-100 issue cycles, eight of them in
+                    // a row at the top of the chunk left the MFMA pipe idle for most of a k-step
+                    if (j == 0) {
+                        if (s_ + 1 < NS) load_ops(Xc, Wc, s_ + 1, d[(s_ + 1) & 1], a[(s_ + 1) & 1]);
+                        if (s_ == NS - 1 && nextc) commit_raw(cur ^ 1);
+                    }
+                    const int q = s_ * 8 + j;
+                    if (nextc) {                      // the other buffer was last read one chunk ago (barrier since)
+#ifndef C2S_WN_NO_U
+                        if (q < WPT) stage_u_piece(cb_ + CK, cur ^ 1, q);
+#endif
+#ifndef C2S_WN_NO_RAW
+                        if (q >= WPT && q < WPT + MAXE) prefetch_raw_piece(cb_ + CK, q - WPT);
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#ifndef C2S_WN_NO_BAR
+            __syncthreads();
+#endif
+        }
+        WN_STAMP(3);
+        // `cur` now names the buffer the NEXT chunk would use: it was last read two barriers ago and is free; the
+        // exchange area of the epilogue lives in the other one.
+
+        // ---- finished tile: output position of this lane's 2x2 block; then start the next tile's first requests
+        const int oy = oy0 + 2 * by, ox = ox0 + 2 * bx;
+        const bool inb = oy < p.H && ox < p.W;
+        float* on = p.out + (size_t)n * p.Cout * HW + (size_t)oy * p.W + ox;
+        t = next_valid(t + gridDim.x);
+        const bool more = t < ntotal;
+        if (more) {
+            begin_tile(t);
+            stage_u(0, cur);                          // in flight during the epilogue
+            prefetch_raw(0);
+        }
+
+        // ---- epilogue, one 32-channel half at a time.  nu side of the output transform in registers:
+        //      P[x] = sum_nu M[nu] A[nu][x]; exchange [xi 4][x 2][r 16][lane 64]
+        WN_STAMP(4);
+        // Barriers of the epilogue order LDS traffic only: a raw s_barrier behind lgkmcnt(0) -- __syncthreads() would
+        // also wait for vmcnt(0), i.e. for the next tile's requests that are meant to stay in flight here.
+        auto lds_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        float* ex = lds + (cur ^ 1) * BUF;
+        const bool odd = (lane & 1) != 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m == 1) lds_barrier();                // first half fully read
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
+                ex[((xi * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
+                ex[((xi * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+            }
+            lds_barrier();
+            if (m == 0) WN_STAMP(5); else WN_STAMP(7);
+            // xi side: Y[0][x] = P0 + P1 + P2, Y[1][x] = P1 - P2 - P3; wave w finishes accumulator rows r with r>>2 == w.
+            // Neighbouring lanes (blocks bx, bx+1) swap one row each so that every lane stores ONE float4 (4 pixels of
+            // a row): even lanes write row 0 of both blocks, odd lanes row 1.
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = xi * 4 + rr;
+                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float P[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) P[q][x] = ex[((q * 2 + x) * 16 + r) * 64 + lane];
+                const float y00 = P[0][0] + P[1][0] + P[2][0], y01 = P[0][1] + P[1][1] + P[2][1];
+                const float y10 = P[1][0] - P[2][0] - P[3][0], y11 = P[1][1] - P[2][1] - P[3][1];
+                // send the row the partner stores, receive the partner's share of the row this lane stores
+                const float s0 = odd ? y00 : y10, s1 = odd ? y01 : y11;
+                const float g0 = __shfl_xor(s0, 1, 64), g1 = __shfl_xor(s1, 1, 64);
+                f32x4 v = odd ? f32x4{g0, g1, y10, y11} : f32x4{y00, y01, g0, g1};
+                if (inb && co < p.Cout) {
+                    if (p.bias != nullptr) v += p.bias[co];
+                    // even lane: row oy, columns ox..ox+3 ; odd lane: row oy+1, columns ox-2..ox+1
+                    f32x4* dst = reinterpret_cast<f32x4*>(on + (size_t)co * HW + (odd ? p.W - 2 : 0));
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
             }
         }
-        __syncthreads();
+        WN_STAMP(6);
+        if (!more) break;
+        // no barrier needed here: the next commit writes the X area of buffer `cur`, the exchange lived in the other
+        // buffer, and the barrier after that commit orders every later write to it.
     }
-
-    // ---- epilogue.  nu side of the output transform in registers: P[x] = sum_nu M[nu] A[nu][x]
-    float* ex = lds;                                 // [xi 4][x 2][m*16+r 32][lane 64]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
-            ex[((xi * 2 + 0) * 32 + m * 16 + r) * 64 + lane] = m0 + m1 + m2;
-            ex[((xi * 2 + 1) * 32 + m * 16 + r) * 64 + lane] = m1 - m2 - m3;
-        }
-    __syncthreads();
-    // xi side: Y[0][x] = P0 + P1 + P2, Y[1][x] = P1 - P2 - P3; wave w finishes the accumulator rows r with r>>2 == w
-    const int oy = oy0 + 2 * by, ox = ox0 + 2 * bx;
-    if (oy >= p.H || ox >= p.W) return;
-    float* on = p.out + (size_t)n * p.Cout * HW + (size_t)oy * p.W + ox;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = xi * 4 + rr;
-            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (co >= p.Cout) continue;
-            float P[4][2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int x = 0; x < 2; ++x) P[q][x] = ex[((q * 2 + x) * 32 + m * 16 + r) * 64 + lane];
-            f32x2 y0 = {P[0][0] + P[1][0] + P[2][0], P[0][1] + P[1][1] + P[2][1]};
-            f32x2 y1 = {P[1][0] - P[2][0] - P[3][0], P[1][1] - P[2][1] - P[3][1]};
-            if (p.bias != nullptr) { const float bv = p.bias[co]; y0 += bv; y1 += bv; }
-            f32x2* d0 = reinterpret_cast<f32x2*>(on + (size_t)co * HW);
-            f32x2* d1 = reinterpret_cast<f32x2*>(on + (size_t)co * HW + p.W);
-            if (p.accumulate) { y0 += *d0; y1 += *d1; }
-            *d0 = y0;
-            *d1 = y1;
-        }
+    WN_STAMP_FLUSH;
 }
 
 struct TapTable9 {
     int off[9];
 };
 
-// U[xi][nu][c][o] = (G g Gt)[xi][nu] of the 3x3 filter g[k] = src[o*so + c*sc + tap[k]]
+// U = G g Gt of the 3x3 filter g[k] = src[o*so + c*sc + tap[k]], stored [cout block][chunk][xn 16][c 8][o 64]
+// (zero for channels / outputs past the real counts)
 __global__ void pack_winograd_kernel(const float* __restrict__ src, float* __restrict__ upk, int cin, int cout, int coutP,
                                      long so, long sc, TapTable9 tt) {
-    const long total = (long)cin * coutP;
+    const int nchunks = (cin + WN_CK - 1) / WN_CK;
+    const long total = (long)nchunks * WN_CK * coutP;
     const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int o = (int)(e % coutP), c = (int)(e / coutP);
+    const bool real = o < cout && c < cin;
     float g[3][3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = o < cout ? src[o * so + c * sc + tt.off[k]] : 0.f;
+    for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = real ? src[o * so + c * sc + tt.off[k]] : 0.f;
     float t[4][3];                                  // G g
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -297,20 +392,27 @@ __global__ void pack_winograd_kernel(const float* __restrict__ src, float* __res
         t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
         t[3][j] = g[2][j];
     }
+    float* base = upk + ((size_t)(o >> 6) * nchunks + (c >> 3)) * WN_USLAB + (c & 7) * 64 + (o & 63);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float u0 = t[i][0];
-        const float u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-        const float u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-        const float u3 = t[i][2];
-        upk[((size_t)(i * 4 + 0) * cin + c) * coutP + o] = u0;
-        upk[((size_t)(i * 4 + 1) * cin + c) * coutP + o] = u1;
-        upk[((size_t)(i * 4 + 2) * cin + c) * coutP + o] = u2;
-        upk[((size_t)(i * 4 + 3) * cin + c) * coutP + o] = u3;
+        base[(i * 4 + 0) * WN_CK * 64] = t[i][0];
+        base[(i * 4 + 1) * WN_CK * 64] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+        base[(i * 4 + 2) * WN_CK * 64] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+        base[(i * 4 + 3) * WN_CK * 64] = t[i][2];
     }
 }
 
 }  // namespace
+
+extern "C" size_t c2s_winograd_packed_floats(int cin, int coutP) {
+    return (size_t)(coutP / 64) * cdiv(cin, WN_CK) * WN_USLAB;
+}
+
+#ifdef C2S_WN_STAMP
+extern "C" int c2s_debug_winograd_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wn_stamps), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int c2s_pack_weights_winograd(const float* src, float* upk, int cin, int cout, int coutP, long stride_o,
                                          long stride_c, const int* host_tap_off, void* stream) {
@@ -318,7 +420,7 @@ extern "C" int c2s_pack_weights_winograd(const float* src, float* upk, int cin, 
     C2S_REQUIRE(coutP % 64 == 0 && coutP >= cout && cin > 0, "pack_weights_winograd: CoutP must be a multiple of 64");
     TapTable9 tt;
     for (int i = 0; i < 9; ++i) tt.off[i] = host_tap_off[i];
-    const long total = (long)cin * coutP;
+    const long total = (long)cdiv(cin, WN_CK) * WN_CK * coutP;
     hipLaunchKernelGGL(pack_winograd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, upk, cin, cout,
                        coutP, stride_o, stride_c, tt);
     C2S_CHECK_LAUNCH("pack_weights_winograd");
@@ -332,7 +434,7 @@ extern "C" int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, c
     C2S_REQUIRE(d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1, "conv3x3_winograd: 3x3 stride 1 pad 1 only");
     C2S_REQUIRE(d->Hout == d->Hin && d->Wout == d->Win && d->OutH == d->Hout && d->OutW == d->Wout && d->osy == 1 &&
                 d->osx == 1 && d->ooy == 0 && d->oox == 0, "conv3x3_winograd: dense same-size output only");
-    C2S_REQUIRE(d->Hin % 2 == 0 && d->Win % 2 == 0 && d->Hin >= 2 && d->Win >= 8, "conv3x3_winograd: even planes, W >= 8");
+    C2S_REQUIRE(d->Hin % 2 == 0 && d->Win % 4 == 0 && d->Hin >= 2 && d->Win >= 8, "conv3x3_winograd: even H, W a multiple of 4 and >= 8");
     C2S_REQUIRE(d->CoutP % 64 == 0 && d->CoutP >= d->Cout && d->Cout > 0, "conv3x3_winograd: CoutP must be a multiple of 64");
     C2S_REQUIRE(d->C1 == 0 || d->C0 % WN_CK == 0, "conv3x3_winograd: with two sources C0 must be a multiple of 8");
     C2S_REQUIRE((long)(d->C0 > d->C1 ? d->C0 : d->C1) * d->Hin * d->Win * 4 < (1L << 31), "conv3x3_winograd: frame too large");
@@ -343,23 +445,47 @@ extern "C" int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, c
     p.pad_mode = d->pad_mode; p.accumulate = d->accumulate;
     int l2 = 4;
     while (l2 > 2 && (2 << l2) > d->Win) --l2;
-    p.log2bc = l2;
     const int BC = 1 << l2, BR = 32 >> l2;
     p.tiles_x = cdiv(d->Win, 2 * BC);
-    const int tiles = p.tiles_x * cdiv(d->Hin, 2 * BR);
+    p.tiles = p.tiles_x * cdiv(d->Hin, 2 * BR);
+    p.N = d->N;
+    p.nchunks = cdiv(d->C0 + d->C1, WN_CK);
     const int plane = (2 * BR + 2) * (2 * BC + 2);
     size_t fl = 2 * ((size_t)WN_CK * plane + WN_USLAB);
     if (fl < (size_t)WN_EXCH) fl = WN_EXCH;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    dim3 grid(tiles, d->CoutP / 64, d->N);
+    // persistent workgroups: two per CU (register / LDS limit), split over the output-channel blocks
+    const int cblocks = d->CoutP / 64;
+    const long ntotal = (long)d->N * p.tiles;
+    int wpc = 2;
+#ifdef C2S_WN_STAMP
+    if (const char* e = getenv("C2S_WN_WGS_PER_CU")) wpc = atoi(e);     // diagnostic build: solo-workgroup timing
+#endif
+    long gx = ((long)wpc * cus + cblocks - 1) / cblocks;
+    if (gx > ntotal) gx = ntotal;
+    dim3 grid((unsigned)gx, cblocks, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (d->reflect_adjoint) hipLaunchKernelGGL(conv_winograd_kernel<true>, grid, dim3(256), fl * sizeof(float), st, p);
-    else hipLaunchKernelGGL(conv_winograd_kernel<false>, grid, dim3(256), fl * sizeof(float), st, p);
+    const size_t ldsb = fl * sizeof(float);
+#define C2S_WN_LAUNCH(L2_)                                                                                          \
+    if (l2 == L2_) {                                                                                                \
+        if (d->reflect_adjoint) hipLaunchKernelGGL((conv_winograd_kernel<L2_, true>), grid, dim3(256), ldsb, st, p); \
+        else hipLaunchKernelGGL((conv_winograd_kernel<L2_, false>), grid, dim3(256), ldsb, st, p);                   \
+    }
+    C2S_WN_LAUNCH(4)
+    C2S_WN_LAUNCH(3)
+    C2S_WN_LAUNCH(2)
+#undef C2S_WN_LAUNCH
     C2S_CHECK_LAUNCH("conv3x3_winograd");
     return C2S_OK;
 }

@@ -152,7 +152,7 @@ def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, 
     coutP = (cout + 63) // 64 * 64
     if hit is not None:
         return hit, coutP
-    upk = torch.empty(16 * cin * coutP, device=ctx.device, dtype=torch.float32)
+    upk = torch.empty(lib().c2s_winograd_packed_floats(cin, coutP), device=ctx.device, dtype=torch.float32)
     check(lib().c2s_pack_weights_winograd(src.data_ptr() + 4 * src_off, upk.data_ptr(), cin, cout, coutP, so, sc,
                                           _tap_array(taps), _stream()), "pack_weights_winograd")
     ctx._packed[key] = upk
@@ -162,7 +162,7 @@ def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, 
 def _use_winograd(K: int, S: int, pad: int, chans: Sequence[int], cout: int, H: int, W: int) -> bool:
     """Winograd F(2x2,3x3) pays off where the 16 transform-domain GEMMs are deep and wide enough."""
     return (WINOGRAD and CONV_MODE == "f32" and K == 3 and S == 1 and pad == 1 and sum(chans) >= 32 and cout >= 64
-            and H % 2 == 0 and W % 2 == 0 and W >= 8 and (len(chans) == 1 or chans[0] % 8 == 0))
+            and H % 2 == 0 and W % 4 == 0 and W >= 8 and (len(chans) == 1 or chans[0] % 8 == 0))
 
 
 def _use_bf16x3(K: int, S: int, pad: int, chans: Sequence[int]) -> bool:

@@ -100,12 +100,14 @@ int c2s_conv_xpair(const c2s_conv_desc* d, const float* src, const float* wpk, c
  * 3x3 stride-1 pad-1 convolution as Winograd F(2x2,3x3) on the f32 MFMA (2.25x fewer multiplies than
  * c2s_conv_igemm; all arithmetic fp32, error a few 1e-7 of sum|a*b|).  Same descriptor as c2s_conv_igemm with
  * KH = KW = 3, S = 1, pad = 1, dense same-size output, even planes with W >= 8, CoutP a multiple of 64;
- * upk = c2s_pack_weights_winograd ([16][Cin][CoutP] = G g Gt per filter; tap table as for c2s_pack_weights, so the
- * flipped table gives the data-gradient filters).  reflect_adjoint = 1 (zero-padded launch): the adjoint of the
+ * upk = c2s_pack_weights_winograd (G g Gt per filter, c2s_winograd_packed_floats(Cin, CoutP) floats laid out
+ * [cout block of 64][chunk of 8 input channels][16][8][64]; tap table as for c2s_pack_weights, so the flipped table
+ * gives the data-gradient filters).  reflect_adjoint = 1 (zero-padded launch): the adjoint of the
  * reflection is applied to the raw patches of the border blocks inside the kernel.
  * Replaces: nn.Conv2d 3x3 forward (conv.py:70-80,378-382) and its convolution_backward-input for layers with
  * >= 32 input and >= 64 output channels (the engine keeps c2s_conv_igemm for the rest).
  * ------------------------------------------------------------------------------------------------ */
+size_t c2s_winograd_packed_floats(int cin, int coutP);
 int c2s_pack_weights_winograd(const float* src, float* upk, int cin, int cout, int coutP, long stride_o, long stride_c,
                               const int* host_tap_off, void* stream);
 int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
