@@ -30,10 +30,12 @@ import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X dense fp32 MFMA/vector peak (MI355X_MICROARCH.md, chip-level parameters)
 # HBM bytes of ONE launch of the dominant kernel (64->64 3x3 @128x128, N=128): rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate passes (profiles/r01_pmc_conv3x3_64x64_128px.csv): 822,877 KiB + 524,288 KiB.
+# --pmc WRITE_SIZE in separate passes (profiles/r01_pmc_winograd_64x64_128px.csv): 995,960 KiB + 524,288 KiB.
 # FETCH_SIZE is quoted uncorrected: the x2 correction of the micro-architecture guide is calibrated for 16-B/lane
-# streaming reads, this kernel gathers 4 B/lane.  Algorithmic bytes: 537 MB in + 537 MB out + 0.15 MB weights.
-DOMINANT_KERNEL_TRAFFIC_BYTES = (822876.8 + 524288.0) * 1024
+# streaming reads, this kernel gathers 4 B/lane.  Algorithmic bytes: 537 MB in + 537 MB out + 0.15 MB weights
+# (the fetch excess is the halo of the 4x32-pixel tiles: 6x34 / 4x32 = 1.6x).
+DOMINANT_KERNEL_TRAFFIC_BYTES = (995960.4 + 524288.0) * 1024
+DOMINANT_KERNEL_TRAFFIC_BYTES_DIRECT = (822876.8 + 524288.0) * 1024    # C2S_WINOGRAD=0 / bf16x3: conv_igemm_kernel
 
 
 def synthetic_batch(B, T, H, W, seed, device, n_classes=15):
@@ -170,6 +172,23 @@ def main():
         kernel_ms = sum(ms) / max(len(ms), 1)
         flops_launch = 2.0 * (B * T) * 64 * 64 * 9 * H * H           # algorithmic FLOPs of one launch
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12 if ms else 0.0
+        wino = E.WINOGRAD and E.CONV_MODE == "f32"
+        full = B * T == 128 and H == 128
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F32_TFLOPS,
+                    "traffic": (DOMINANT_KERNEL_TRAFFIC_BYTES if wino else DOMINANT_KERNEL_TRAFFIC_BYTES_DIRECT) if full else None,
+                    "kernel": ("conv_winograd_kernel<4,*>" if wino else "conv_igemm_kernel<3,1,2,*>") +
+                              " 64->64 3x3 reflect @128x128 (forward + data-gradient launches)",
+                    "launches_timed": len(ms), "avg_launch_ms": kernel_ms,
+                    "algorithmic_flops_per_launch": flops_launch}
+        if wino:
+            # `achieved` is the ALGORITHMIC (direct-convolution) FLOP count of SURVEY.md 8d over the launch time; the
+            # Winograd F(2x2,3x3) kernel executes 16/36 of those multiplies on the MFMA pipe, so frac may exceed 1.
+            roofline["executed_flops_per_launch"] = flops_launch * 16.0 / 36.0
+            roofline["executed_tflops"] = achieved * 16.0 / 36.0
+            roofline["executed_frac_of_peak"] = achieved * 16.0 / 36.0 / PEAK_F32_TFLOPS
+            roofline["note"] = ("fp32 Winograd F(2x2,3x3): achieved = algorithmic direct-convolution FLOPs / time; "
+                                "executed_* = MFMA FLOPs actually issued (2.25x fewer)")
         out = {
             "metric": "train patches/sec (Tx10x128x128) U-TAE" if args.model == "utae" else f"train patches/sec {args.model}",
             "value": world * B * args.steps / dt,
@@ -186,12 +205,7 @@ def main():
             "config": {"workload": f"{args.model} train step (fwd+CE+bwd+Adam, train mode), B={B}/GPU T={T} 10x{H}x{H}, "
                                    f"random-init weight_init weights, BASELINE.json configs[1] shape in fp32",
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}", "hipgraph": use_graph},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS,
-                         "traffic": DOMINANT_KERNEL_TRAFFIC_BYTES if (B * T == 128 and H == 128) else None,
-                         "kernel": "conv_igemm_kernel<3,1,2,*> 64->64 3x3 reflect @128x128 (forward + data-gradient launches)",
-                         "launches_timed": len(ms), "avg_launch_ms": kernel_ms,
-                         "algorithmic_flops_per_launch": flops_launch},
+            "roofline": roofline,
             "loss": loss_val,
         }
         step_flops = {"utae": (182962 * T + 161216) * H * H * 3.0}.get(args.model)

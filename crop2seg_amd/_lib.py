@@ -77,6 +77,8 @@ SIGNATURES = {
     "c2s_norm_bwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, I, P, P, P, P, P, SZ, P, P]),
     "c2s_frame_flags": (I, [P, P, I, L, F, P]),
     "c2s_ltae_attn_fwd": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P]),
+    "c2s_ltae_fwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
+    "c2s_ltae_attn_fwd_ws": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P, SZ, P]),
     "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_bwd": (I, [C.POINTER(LtaeDesc)] + [P] * 22 + [SZ, P]),
     "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P, P]),

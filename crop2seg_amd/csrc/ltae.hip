@@ -653,6 +653,579 @@ __global__ void dropout_nchw_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------ streaming forward
+// Large pixel counts (TimeUNet runs the L-TAE at full resolution: P = B*128*128, 15.6 KB of x per pixel).
+// lane = pixel: every global access is one 256-byte row segment of 64 adjacent pixels; the per-pixel math is
+// lane-local and the small weight operands (U^T gamma, Wc) come through the scalar cache as SGPR operands.
+// Workgroup = 16 waves on one 64-pixel tile; the role of wave w changes per phase so that nothing needs a
+// cross-lane reduction:
+//   P1 statistics : wave = GroupNorm group   (its C/16 channels, all t)        -> rstd, -mean*rstd via LDS
+//   P2 scores     : wave = time step mod 16  (all channels; 16 head accumulators) -> attn_pre buffer (scratch, L2)
+//   P3 softmax    : wave = head              (all t; dropout; sum_t a, sum_t a*pe stay in registers)
+//   P4 z          : wave = group             (z_raw[h][c] = sum_t a[h,t] x[t,c], 16 x C/16 accumulators)
+//   P5 embedding  : per head through LDS; wave = output row j of the head
+// x is read three times (P1, P2, P4); the second and third pass find part of the tile in the Infinity Cache.
+// Ut [C][16] = U^T * gamma and cU[16] = U beta are prepared by ltae_prep_kernel.
+__global__ void ltae_prep_kernel(const float* __restrict__ U, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float* __restrict__ Ut, float* __restrict__ cU, int C) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < C * NH; e += blockDim.x) {
+        const int c = e / NH, h = e % NH;
+        Ut[e] = U[h * C + c] * gamma[c];
+    }
+    if (tid < NH) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(U[tid * C + c], beta[c], s);
+        cU[tid] = s;
+    }
+}
+
+template <int CPG>
+__global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, const float* __restrict__ Ut,
+                                                                const float* __restrict__ cU) {
+    constexpr int C = CPG * NH;
+    __shared__ float st[NH][2][64];          // rstd, -mean*rstd per (group, pixel)
+    __shared__ float asl[NH][64];            // sum_t attn per (head, pixel)
+    __shared__ float zh[C][64];              // one head's z
+    __shared__ float apl[NH][DV][64];        // sum_t attn * pe per (head, j, pixel)
+    const int T = p.T, HW = p.HW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tiles_per_b = (HW + 63) / 64;
+    const int b = blockIdx.x / tiles_per_b;
+    const int pix0 = (blockIdx.x % tiles_per_b) * 64;
+    const bool act = pix0 + lane < HW;
+    const int pix = act ? pix0 + lane : HW - 1;
+    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
+    const float* xb = p.x + (size_t)b * T * C * HW + pix;          // + (t*C + c)*HW
+
+    // ---- P1: GroupNorm statistics of group w (padded frames included, tae.py:461); shifted sums
+    {
+        const float* xg = xb + (size_t)(w * CPG) * HW;
+        const float K0 = xg[0];
+        float s = 0.f, ss = 0.f;
+        // 4 time steps x CPG channels per batch: >= 16 independent 256-byte loads in flight per wave
+        for (int t0 = 0; t0 < T; t0 += 4) {
+            float v[4][CPG];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u < T ? t0 + u : T - 1;
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) v[u][cc] = xg[(size_t)(t * C + cc) * HW];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + u < T) {
+#pragma unroll
+                    for (int cc = 0; cc < CPG; ++cc) {
+                        const float d = v[u][cc] - K0;
+                        s += d;
+                        ss = fmaf(d, d, ss);
+                    }
+                }
+            }
+        }
+        const float inv_n = 1.f / (float)(CPG * T);
+        const float md = s * inv_n;
+        const float mean = K0 + md;
+        const float var = fmaxf(ss * inv_n - md * md, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        if (act) {
+            p.stats[(pidx * NH + w) * 2] = mean;
+            p.stats[(pidx * NH + w) * 2 + 1] = rstd;
+        }
+        st[w][0][lane] = rstd;
+        st[w][1][lane] = -mean * rstd;
+    }
+    __syncthreads();
+
+    // ---- P2: scores of time steps t = w, w+16, ...   score[h] = s0 + cU[h] + sum_c Ut[c][h] * (x*rstd - mean*rstd)
+    for (int t = w; t < T; t += NH) {
+        float sc[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) sc[h] = p.s0[(b * T + t) * NH + h] + cU[h];
+        const float* xt = xb + (size_t)t * C * HW;
+#pragma unroll 1
+        for (int g0 = 0; g0 < NH; g0 += 4) {       // 4 groups = 16 loads in flight per wave (all 64 would not fit 128 registers)
+            float d[4][CPG];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) d[u][cc] = xt[(size_t)((g0 + u) * CPG + cc) * HW];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float rs = st[g0 + u][0][lane], nm = st[g0 + u][1][lane];
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) {
+                    const float dn = fmaf(d[u][cc], rs, nm);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) sc[h] = fmaf(Ut[((g0 + u) * CPG + cc) * NH + h], dn, sc[h]);
+                }
+            }
+        }
+        const bool padded = p.valid != nullptr && p.valid[b * T + t] == 0;
+        if (act) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                p.attn_pre[((size_t)(h * p.B + b) * T + t) * HW + pix] = padded ? -1e6f : sc[h];      // tae.py:831
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- P3: softmax over T for head w, dropout; sum_t a and sum_t a*pe go to LDS for P5
+    {
+        float asum = 0.f, ape[DV];
+#pragma unroll
+        for (int j = 0; j < DV; ++j) ape[j] = 0.f;
+        float* sp = p.attn_pre + (size_t)(w * p.B + b) * T * HW + pix;
+        float* ap = p.attn + (size_t)(w * p.B + b) * T * HW + pix;
+        // the T <= 64 scores of this (pixel, head) stay in registers: one pass of loads, 16 in flight at a time
+        float sv[64];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            sv[t] = t < T ? sp[(size_t)t * HW] : -3.0e38f;
+        }
+#pragma unroll
+        for (int t = 0; t < 64; ++t) mx = fmaxf(mx, sv[t]);
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            sv[t] = t < T ? __expf(sv[t] - mx) : 0.f;
+            den += sv[t];
+        }
+        const float inv_den = 1.f / den;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            if (t < T) {
+                const float a = sv[t] * inv_den;
+                const float ad = a * keep_scale(p, w, Ptot, pidx, t);
+                if (act) {
+                    sp[(size_t)t * HW] = a;
+                    ap[(size_t)t * HW] = ad;
+                }
+                asum += ad;
+#pragma unroll
+                for (int j = 0; j < DV; ++j) ape[j] = fmaf(ad, p.pe[(b * T + t) * DV + j], ape[j]);
+            }
+        }
+        asl[w][lane] = asum;
+#pragma unroll
+        for (int j = 0; j < DV; ++j) apl[w][j][lane] = ape[j];
+    }
+    if (p.emb == nullptr) return;            // W-TAE: attention masks only (tae.py:619)
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- P4: z_raw[h][c] = sum_t attn[h,t] x[t,c] for the channels of group w (padded frames have attn == 0 exactly)
+    float z[NH][CPG];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int cc = 0; cc < CPG; ++cc) z[h][cc] = 0.f;
+    {
+        const float* xg = xb + (size_t)(w * CPG) * HW;
+        const float* ab = p.attn + (size_t)b * T * HW + pix;          // + (h*B*T + t)*HW
+        for (int t = 0; t < T; ++t) {
+            if (p.valid != nullptr && p.valid[b * T + t] == 0) continue;
+            float xv[CPG], a[NH];
+#pragma unroll
+            for (int cc = 0; cc < CPG; ++cc) xv[cc] = xg[(size_t)(t * C + cc) * HW];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) a[h] = ab[((size_t)h * p.B * T + t) * HW];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) z[h][cc] = fmaf(a[h], xv[cc], z[h][cc]);
+        }
+    }
+    // GroupNorm affine of group w applied after the t-sum: z = A_c * z_raw + B_c * sum_t a
+    float Ac[CPG], Bc[CPG];
+    {
+        const float rstd = st[w][0][lane], nmr = st[w][1][lane];
+#pragma unroll
+        for (int cc = 0; cc < CPG; ++cc) {
+            const float gm = p.gamma[w * CPG + cc];
+            Ac[cc] = gm * rstd;
+            Bc[cc] = fmaf(nmr, gm, p.beta[w * CPG + cc]);
+        }
+    }
+
+    // ---- P5: embedding, one head per round: emb[16h+j] = Wc[16h+j,:].z[h,:] + (sum_t a) bc[16h+j] + sum_t a pe_t[j]
+    for (int h = 0; h < NH; ++h) {
+        const float ah = asl[h][lane];
+#pragma unroll
+        for (int cc = 0; cc < CPG; ++cc) zh[w * CPG + cc][lane] = fmaf(Ac[cc], z[h][cc], Bc[cc] * ah);
+        __syncthreads();
+        {
+            const float* wr = p.Wc + (size_t)(h * DV + w) * C;
+            float o = fmaf(ah, p.bc[h * DV + w], apl[h][w][lane]);
+#pragma unroll 16
+            for (int c = 0; c < C; ++c) o = fmaf(wr[c], zh[c][lane], o);
+            if (act) p.emb[((size_t)b * NH * DV + h * DV + w) * HW + pix] = o;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ streaming backward
+// Same idea as the streaming forward, 32-pixel tiles: lane = (pixel, half), 16 waves per workgroup, the role of a wave
+// changes per phase.  Two kernels (x is read three times in total):
+//  heads kernel
+//   S1 wave = head      r[h][c] = sum_j ge[16h+j] Wc[16h+j][c] -> LDS (128 KB, float4 of 4 channels per pixel);
+//                       c0[h][t] = ge.(bc + pe_t) + g_attn -> GS buffer; sum_t attn; d bc partials
+//   A  wave = t mod 16  half = channel half: dot[h] = sum_c r[h][c] xhat[t][c] (r: ds_read_b128), halves added with one
+//                       cross-lane move; ga = (dot + c0) * keep -> GS buffer
+//   B  wave = head      half = t parity: softmax backward gs = a' (ga - sum_t a' ga) -> GS buffer; d s0 partials
+//   C  wave = group     half = channel pair: V_raw = sum_t gs x, Z_raw = sum_t attn x (attn / gs of 4 time steps at a
+//                       time staged in LDS as [t][h/4][pixel][4]); GroupNorm-backward means m1, m2 per (pixel, group)
+//                       in closed form from r, U, V, Z (no pass over t); Z -> global (d Wc), d U / d gamma / d beta partials
+//  gx kernel
+//   X  wave = group     half = channel pair: d xhat[t][c] = sum_h attn[h,t] r[h][c] + gs[h,t] U[h][c];
+//                       gx = rstd (gamma d xhat - m1 - xn m2)
+constexpr int SPT = 32;      // pixels per streaming backward tile
+constexpr int SCH = 4;       // time steps per staged attn / gs chunk
+
+struct StreamBwd {
+    float* M;        // [P][16][2]  m1, m2
+    float* part_U;   // [tiles][16][C]
+};
+
+__device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes of this half of the wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// stage attn and gs of time steps [t0, t0+SCH) for the tile's pixels: LDS [arr 2][SCH][h/4][32 px][4]
+__device__ __forceinline__ void stage_heads_chunk(const LtaeParams& p, float* buf, int b, int pix, int t0, int w, int px, int hf,
+                                                  const float* gs_src) {
+    // 2 arrays x SCH x 16 heads = 128 rows of 32 pixels; wave w loads rows [8w, 8w+8): 4 per half
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w * 8 + hf * 4 + i;
+        const int arr = row >> 6, rem = row & 63;
+        const int tt = rem >> 4, h = rem & 15;
+        const int t = t0 + tt;
+        float v = 0.f;
+        if (t < p.T) {
+            const size_t o = ((size_t)(h * p.B + b) * p.T + t) * p.HW + pix;
+            v = arr == 0 ? p.attn_in[o] : gs_src[o];
+        }
+        buf[(((arr * SCH + tt) * 4 + (h >> 2)) * SPT + px) * 4 + (h & 3)] = v;
+    }
+}
+
+template <int CPG>
+__global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams p, StreamBwd sb) {
+    constexpr int C = CPG * NH;
+    static_assert(CPG == 4, "lane halves own channel pairs of a 4-channel group");
+    extern __shared__ float lds[];
+    float* rl = lds;                               // [16 h][C/4][32 px][4]        128 KB
+    float* stl = rl + NH * C * SPT;                // [16 g][2][32]  rstd, -mean*rstd
+    float* asl = stl + NH * 2 * SPT;               // [16 h][32]     sum_t attn
+    float* gsl = asl + NH * SPT;                   // [16 h][32]     sum_t gs
+    float* chk = gsl + NH * SPT;                   // [2][SCH][4][32][4]  staged attn / gs chunk   16 KB
+    const int T = p.T, HW = p.HW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = lane & 31, hf = lane >> 5;
+    const int tiles_per_b = (HW + SPT - 1) / SPT;
+    const int b = blockIdx.x / tiles_per_b;
+    const int pix0 = (blockIdx.x % tiles_per_b) * SPT;
+    const bool act = pix0 + px < HW;
+    const int pix = act ? pix0 + px : HW - 1;
+    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
+    const float* xb = p.x + (size_t)b * T * C * HW + pix;
+
+    // ---- S1: wave = head
+    {
+        const int h = w;
+        if (hf == 0) {
+            stl[(h * 2 + 0) * SPT + px] = p.stats_in[(pidx * NH + h) * 2 + 1];
+            stl[(h * 2 + 1) * SPT + px] = -p.stats_in[(pidx * NH + h) * 2] * p.stats_in[(pidx * NH + h) * 2 + 1];
+        }
+        float ge[DV];
+#pragma unroll
+        for (int j = 0; j < DV; ++j) ge[j] = p.g_emb[((size_t)b * NH * DV + h * DV + j) * HW + pix];
+        // r[h][c] for all channels (weights stay wave-uniform = scalar operands; both halves compute, each half stores
+        // the channels it will read in phase A)
+#pragma unroll 2
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                const float* wr = p.Wc + (size_t)(h * DV + j) * C + c4 * 4;
+                r[0] = fmaf(ge[j], wr[0], r[0]); r[1] = fmaf(ge[j], wr[1], r[1]);
+                r[2] = fmaf(ge[j], wr[2], r[2]); r[3] = fmaf(ge[j], wr[3], r[3]);
+            }
+            if ((c4 >> 3) == hf) *reinterpret_cast<f32x4*>(rl + ((size_t)(h * (C / 4) + c4) * SPT + px) * 4) = r;
+        }
+        float gebc = 0.f;
+#pragma unroll
+        for (int j = 0; j < DV; ++j) gebc = fmaf(ge[j], p.bc[h * DV + j], gebc);
+        float asum = 0.f;
+        for (int t = hf; t < T; t += 2) {
+            const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
+            float c0 = gebc + (p.g_attn != nullptr ? p.g_attn[o] : 0.f);
+#pragma unroll
+            for (int j = 0; j < DV; ++j) c0 = fmaf(ge[j], p.pe[(b * T + t) * DV + j], c0);
+            asum += p.attn_in[o];
+            if (act) p.GS[o] = c0;
+        }
+        asum += __shfl_xor(asum, 32, 64);
+        if (hf == 0) asl[h * SPT + px] = asum;
+        // d bc[16h+j] = sum_px ge[j] * sum_t attn      (half 0 reduces j < 8, half 1 the rest)
+#pragma unroll
+        for (int jj = 0; jj < DV / 2; ++jj) {
+            const int j = hf * (DV / 2) + jj;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < DV; ++k) v = k == j ? ge[k] : v;
+            v = half_sum32(act ? v * asum : 0.f);
+            if (px == 0) p.part_bc[(size_t)blockIdx.x * NH * DV + h * DV + j] = v;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- A: wave = time steps t = w, w+16, ...; half = channels [32 hf, 32 hf + 32)
+    for (int t = w; t < T; t += NH) {
+        const float* xt = xb + (size_t)(t * C + hf * (C / 2)) * HW;
+        float xh[C / 2];
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) xh[i] = xt[(size_t)i * HW];
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) {
+            const int c = hf * (C / 2) + i, g = c / CPG;
+            const float dn = fmaf(xh[i], stl[(g * 2 + 0) * SPT + px], stl[(g * 2 + 1) * SPT + px]);
+            const float gm = hf ? p.gamma[C / 2 + i] : p.gamma[i], bt = hf ? p.beta[C / 2 + i] : p.beta[i];   // scalar loads + select
+            xh[i] = fmaf(dn, gm, bt);
+        }
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) {
+            const float* rr = rl + ((size_t)(h * (C / 4) + hf * (C / 8)) * SPT + px) * 4;
+            float dot = 0.f;
+#pragma unroll
+            for (int i4 = 0; i4 < C / 8; ++i4) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(rr + (size_t)i4 * SPT * 4);
+                dot = fmaf(r[0], xh[4 * i4 + 0], dot); dot = fmaf(r[1], xh[4 * i4 + 1], dot);
+                dot = fmaf(r[2], xh[4 * i4 + 2], dot); dot = fmaf(r[3], xh[4 * i4 + 3], dot);
+            }
+            dot += __shfl_xor(dot, 32, 64);
+            const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
+            const float ga = (dot + p.GS[o]) * keep_scale(p, h, Ptot, pidx, t);
+            if (act && hf == 0) p.GS[o] = ga;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- B: wave = head; half = t parity
+    {
+        const int h = w;
+        const size_t o0 = (size_t)(h * p.B + b) * T * HW + pix;
+        float dsum = 0.f;
+        for (int t = hf; t < T; t += 2) dsum = fmaf(p.attn_pre_in[o0 + (size_t)t * HW], p.GS[o0 + (size_t)t * HW], dsum);
+        dsum += __shfl_xor(dsum, 32, 64);
+        float gssum = 0.f;
+        for (int t = hf; t < T; t += 2) {
+            const float gs = p.attn_pre_in[o0 + (size_t)t * HW] * (p.GS[o0 + (size_t)t * HW] - dsum);
+            if (act) p.GS[o0 + (size_t)t * HW] = gs;
+            gssum += gs;
+            const float r = half_sum32(act ? gs : 0.f);            // d s0[b,t,h]: sum over the pixels of the tile
+            if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + h] = r;
+        }
+        gssum += __shfl_xor(gssum, 32, 64);
+        if (hf == 0) gsl[h * SPT + px] = gssum;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- C: wave = group g; half = channel pair (c0, c0+1) = 4g + 2hf
+    {
+        const int g = w, c0 = g * CPG + 2 * hf;
+        float Vr[NH][2], Zr[NH][2];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { Vr[h][0] = Vr[h][1] = Zr[h][0] = Zr[h][1] = 0.f; }
+        const float* xg = xb + (size_t)c0 * HW;
+        for (int t0 = 0; t0 < T; t0 += SCH) {
+            __syncthreads();                                     // previous chunk consumed
+            stage_heads_chunk(p, chk, b, pix, t0, w, px, hf, p.GS);
+            float xv[SCH][2];
+#pragma unroll
+            for (int tt = 0; tt < SCH; ++tt) {
+                const int t = t0 + tt < T ? t0 + tt : T - 1;
+                xv[tt][0] = xg[(size_t)(t * C) * HW];
+                xv[tt][1] = xg[(size_t)(t * C + 1) * HW];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < SCH; ++tt) {
+                if (t0 + tt < T) {
+#pragma unroll
+                    for (int hq = 0; hq < 4; ++hq) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(chk + (((0 * SCH + tt) * 4 + hq) * SPT + px) * 4);
+                        const f32x4 gs = *reinterpret_cast<const f32x4*>(chk + (((1 * SCH + tt) * 4 + hq) * SPT + px) * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            Zr[hq * 4 + k][0] = fmaf(a[k], xv[tt][0], Zr[hq * 4 + k][0]);
+                            Zr[hq * 4 + k][1] = fmaf(a[k], xv[tt][1], Zr[hq * 4 + k][1]);
+                            Vr[hq * 4 + k][0] = fmaf(gs[k], xv[tt][0], Vr[hq * 4 + k][0]);
+                            Vr[hq * 4 + k][1] = fmaf(gs[k], xv[tt][1], Vr[hq * 4 + k][1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // two ds_read_b128 at a time (all 32 hoisted = 128 registers)
+                    }
+                }
+            }
+        }
+        // normalised sums: sum_t w xn = rstd * W_raw - mean rstd * sum_t w
+        const float rs = stl[(g * 2 + 0) * SPT + px], nm = stl[(g * 2 + 1) * SPT + px];
+        float gmk[2], btk[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            gmk[k] = hf ? p.gamma[g * CPG + 2 + k] : p.gamma[g * CPG + k];      // scalar loads + select
+            btk[k] = hf ? p.beta[g * CPG + 2 + k] : p.beta[g * CPG + k];
+        }
+        float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float as = asl[h * SPT + px], gss = gsl[h * SPT + px];
+            float* rp = rl + ((size_t)(h * (C / 4) + g) * SPT + px) * 4 + 2 * hf;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = c0 + k;
+                const float zt = fmaf(rs, Zr[h][k], nm * as);
+                const float vt = fmaf(rs, Vr[h][k], nm * gss);
+                const float u = hf ? p.U[h * C + g * CPG + 2 + k] : p.U[h * C + g * CPG + k];
+                const float r = rp[k];
+                dg[k] += r * zt + u * vt;
+                db[k] += r * as + u * gss;
+                // Z (xhat-based) for d Wc; V (xhat-based) for d U replaces r in LDS (only this lane reads that slot)
+                if (act) p.Z[(((size_t)b * NH + h) * C + c) * HW + pix] = fmaf(gmk[k], zt, btk[k] * as);
+                rp[k] = act ? fmaf(gmk[k], vt, btk[k] * gss) : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // one head at a time: keeps the store addresses from all being live
+        }
+        // d gamma / d beta partials of the tile; GroupNorm-backward means of the group
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = c0 + k;
+            const float gm = hf ? p.gamma[g * CPG + 2 + k] : p.gamma[g * CPG + k];
+            m1 = fmaf(gm, db[k], m1);
+            m2 = fmaf(gm, dg[k], m2);
+            const float sg = half_sum32(act ? dg[k] : 0.f), sbt = half_sum32(act ? db[k] : 0.f);
+            if (px == 0) {
+                p.part_gb[((size_t)blockIdx.x * C + c) * 2 + 0] = sg;
+                p.part_gb[((size_t)blockIdx.x * C + c) * 2 + 1] = sbt;
+            }
+        }
+        m1 += __shfl_xor(m1, 32, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        const float inv_n = 1.f / (float)(CPG * T);
+        if (act && hf == 0) {
+            sb.M[(pidx * NH + g) * 2 + 0] = m1 * inv_n;
+            sb.M[(pidx * NH + g) * 2 + 1] = m2 * inv_n;
+        }
+    }
+    __syncthreads();
+    // d U partial of the tile: thread = (head, channel), fixed-order sum over the 32 pixels (rotated start: no bank conflicts)
+    {
+        const int h = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const float* vp = rl + (size_t)(h * (C / 4) + (c >> 2)) * SPT * 4 + (c & 3);
+        float sum = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < SPT; ++i) sum += vp[((i + (c >> 2)) & (SPT - 1)) * 4];
+        sb.part_U[((size_t)blockIdx.x * NH + h) * C + c] = sum;
+    }
+}
+
+template <int CPG>
+__global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, StreamBwd sb) {
+    constexpr int C = CPG * NH;
+    __shared__ float chk[2 * SCH * 4 * SPT * 4];              // staged attn / gs chunk
+    __shared__ float gel[NH * DV * SPT];                      // g_emb of the tile, [h][j/4][32 px][4]
+    const int T = p.T, HW = p.HW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = lane & 31, hf = lane >> 5;
+    const int tiles_per_b = (HW + SPT - 1) / SPT;
+    const int b = blockIdx.x / tiles_per_b;
+    const int pix0 = (blockIdx.x % tiles_per_b) * SPT;
+    const bool act = pix0 + px < HW;
+    const int pix = act ? pix0 + px : HW - 1;
+    const long pidx = (long)b * HW + pix;
+    const int g = w, c0 = g * CPG + 2 * hf;
+    // g_emb rows of head w -> LDS (every wave needs all 256 of them)
+#pragma unroll
+    for (int i = 0; i < DV / 2; ++i) {
+        const int j = hf * (DV / 2) + i;
+        gel[((w * (DV / 4) + (j >> 2)) * SPT + px) * 4 + (j & 3)] = p.g_emb[((size_t)b * NH * DV + w * DV + j) * HW + pix];
+    }
+    __syncthreads();
+    // r and U of the two channels of this lane.  The four channels of the group are computed with wave-uniform
+    // (scalar) weights and the half selects its pair.
+    float r[NH][2], u[NH][2];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        float ra[CPG] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jq = 0; jq < DV / 4; ++jq) {
+            const f32x4 ge = *reinterpret_cast<const f32x4*>(gel + ((h * (DV / 4) + jq) * SPT + px) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* wr = p.Wc + (size_t)(h * DV + jq * 4 + k) * C + g * CPG;
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) ra[cc] = fmaf(ge[k], wr[cc], ra[cc]);
+            }
+        }
+        r[h][0] = hf ? ra[2] : ra[0];
+        r[h][1] = hf ? ra[3] : ra[1];
+        u[h][0] = hf ? p.U[h * C + g * CPG + 2] : p.U[h * C + g * CPG + 0];
+        u[h][1] = hf ? p.U[h * C + g * CPG + 3] : p.U[h * C + g * CPG + 1];
+    }
+    const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
+    const float m1 = sb.M[(pidx * NH + g) * 2 + 0], m2 = sb.M[(pidx * NH + g) * 2 + 1];
+    const float gm0 = (hf ? p.gamma[g * CPG + 2] : p.gamma[g * CPG]) * rstd, gm1 = (hf ? p.gamma[g * CPG + 3] : p.gamma[g * CPG + 1]) * rstd;
+    const float* xg = p.x + (size_t)b * T * C * HW + (size_t)c0 * HW + pix;
+    float* gxg = p.gx + (size_t)b * T * C * HW + (size_t)c0 * HW + pix;
+    for (int t0 = 0; t0 < T; t0 += SCH) {
+        __syncthreads();
+        stage_heads_chunk(p, chk, b, pix, t0, w, px, hf, p.GS);
+        float xv[SCH][2];
+#pragma unroll
+        for (int tt = 0; tt < SCH; ++tt) {
+            const int t = t0 + tt < T ? t0 + tt : T - 1;
+            xv[tt][0] = xg[(size_t)(t * C) * HW];
+            xv[tt][1] = xg[(size_t)(t * C + 1) * HW];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < SCH; ++tt) {
+            const int t = t0 + tt;
+            if (t < T) {
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int hq = 0; hq < 4; ++hq) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(chk + (((0 * SCH + tt) * 4 + hq) * SPT + px) * 4);
+                    const f32x4 gs = *reinterpret_cast<const f32x4*>(chk + (((1 * SCH + tt) * 4 + hq) * SPT + px) * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int h = hq * 4 + k;
+                        d0 = fmaf(a[k], r[h][0], d0); d0 = fmaf(gs[k], u[h][0], d0);
+                        d1 = fmaf(a[k], r[h][1], d1); d1 = fmaf(gs[k], u[h][1], d1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (act) {
+                    const float xn0 = (xv[tt][0] - mean) * rstd, xn1 = (xv[tt][1] - mean) * rstd;
+                    gxg[(size_t)(t * C) * HW] = gm0 * d0 - rstd * fmaf(xn0, m2, m1);
+                    gxg[(size_t)(t * C + 1) * HW] = gm1 * d1 - rstd * fmaf(xn1, m2, m1);
+                }
+            }
+        }
+    }
+}
+
 size_t fwd_lds(const c2s_ltae_desc* d) {
     const size_t CH = d->C > 64 ? 64 : d->C;
     return ((size_t)d->C * 32 + (size_t)d->T * 256 + 256 + NH * CH * 16) * 4;
@@ -685,10 +1258,26 @@ void fill(LtaeParams& p, const c2s_ltae_desc* d) {
 
 }  // namespace
 
-extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
-                                 const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
-                                 const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
-                                 void* stream) {
+extern "C" size_t c2s_ltae_fwd_workspace_floats(const c2s_ltae_desc* d) {
+    if (!d) return 0;
+    return (size_t)d->C * NH + NH;          // Ut [C][16], cU [16] of the streaming path
+}
+
+// The streaming kernels pay off once the 64-pixel tiles fill the chip; below that the 16-pixel LDS kernel is used.
+static bool use_stream(const c2s_ltae_desc* d) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return d->C == 64 && (long)d->B * ((d->HW + 63) / 64) >= 2L * cus;
+}
+
+extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                                    const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                                    const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
+                                    float* workspace, size_t ws_floats, void* stream) {
     if (int rc = check(d)) return rc;
     C2S_REQUIRE(x && gamma && beta && U && s0 && attn && stats, "ltae_fwd: null pointer");
     C2S_REQUIRE(emb == nullptr || (Wc && bc && pe), "ltae_fwd: embedding output needs Wc, bc, pe");
@@ -696,15 +1285,33 @@ extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const f
     fill(p, d);
     p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.s0 = s0; p.Wc = Wc; p.bc = bc; p.pe = pe; p.valid = valid;
     p.attn = attn; p.attn_pre = attn_pre; p.emb = emb; p.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    if (workspace != nullptr && attn_pre != nullptr && use_stream(d)) {
+        C2S_REQUIRE(ws_floats >= c2s_ltae_fwd_workspace_floats(d), "ltae_fwd: workspace too small");
+        float* Ut = workspace;
+        float* cU = workspace + (size_t)d->C * NH;
+        hipLaunchKernelGGL(ltae_prep_kernel, dim3(1), dim3(256), 0, st, U, gamma, beta, Ut, cU, d->C);
+        C2S_CHECK_LAUNCH("ltae_prep");
+        hipLaunchKernelGGL(ltae_stream_fwd_kernel<4>, dim3(d->B * ((d->HW + 63) / 64)), dim3(1024), 0, st, p, Ut, cU);
+        C2S_CHECK_LAUNCH("ltae_stream_fwd");
+        return C2S_OK;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * ((d->HW + 15) / 16)), dim3(256), fwd_lds(d), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * ((d->HW + 15) / 16)), dim3(256), fwd_lds(d), st, p);
     C2S_CHECK_LAUNCH("ltae_fwd");
     return C2S_OK;
+}
+
+extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                                 const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                                 const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
+                                 void* stream) {
+    return c2s_ltae_attn_fwd_ws(d, x, gamma, beta, U, s0, Wc, bc, pe, valid, attn, attn_pre, emb, stats, nullptr, 0, stream);
 }
 
 // workspace: GS [16,B,T,HW] | V [B,16,C,HW] | Z [B,16,C,HW] | part_s0 [tiles][T][16] | part_bc [tiles][256]
@@ -728,7 +1335,8 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
                 "ltae_bwd: null pointer");
     C2S_REQUIRE(ws_floats >= c2s_ltae_bwd_workspace_floats(d), "ltae_bwd: workspace too small");
     (void)s0; (void)valid;
-    const int PT = bwd_pt(d);
+    const bool stream_path = g_emb != nullptr && use_stream(d);
+    const int PT = stream_path ? SPT : bwd_pt(d);
     const size_t tiles = (size_t)d->B * ((d->HW + PT - 1) / PT);
     const size_t tiles_ws = (size_t)d->B * ((d->HW + 7) / 8);
     LtaeParams p = {};
@@ -746,12 +1354,25 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_stream_bwd_heads_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
-    C2S_CHECK_LAUNCH("ltae_bwd_heads");
-    hipLaunchKernelGGL(ltae_bwd_gx_kernel, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
-    C2S_CHECK_LAUNCH("ltae_bwd_gx");
+    StreamBwd sb = {};
+    if (stream_path) {
+        // the V area of the workspace is not used by the streaming kernels: it holds M [P][16][2] and part_U [tiles][16][C]
+        sb.M = p.V;
+        sb.part_U = p.V + (size_t)d->B * d->HW * NH * 2;
+        const size_t lds1 = ((size_t)NH * d->C * SPT + NH * 2 * SPT + 2 * NH * SPT + 2 * SCH * 4 * SPT * 4) * sizeof(float);
+        hipLaunchKernelGGL(ltae_stream_bwd_heads_kernel<4>, dim3(tiles), dim3(1024), lds1, st, p, sb);
+        C2S_CHECK_LAUNCH("ltae_stream_bwd_heads");
+        hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), 0, st, p, sb);
+        C2S_CHECK_LAUNCH("ltae_stream_bwd_gx");
+    } else {
+        hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
+        C2S_CHECK_LAUNCH("ltae_bwd_heads");
+        hipLaunchKernelGGL(ltae_bwd_gx_kernel, dim3(tiles), dim3(256), bwd2_lds(d), st, p);
+        C2S_CHECK_LAUNCH("ltae_bwd_gx");
+    }
     // reductions
     const int tpb = (d->HW + PT - 1) / PT;
     {   // gs0[b][t][h] = sum over the tiles of b
@@ -770,7 +1391,12 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         hipMemcpy2DAsync(ggamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
         hipMemcpy2DAsync(gbeta, sizeof(float), gb + 1, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
     }
-    hipLaunchKernelGGL(sum_over_pixels_kernel, dim3(NH * d->C), dim3(64), 0, st, p.V, gU, d->B, NH * d->C, d->HW);
+    if (stream_path) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(NH * d->C), dim3(64), 0, st, sb.part_U, gU, (int)tiles, NH * d->C,
+                           (long)NH * d->C);
+    } else {
+        hipLaunchKernelGGL(sum_over_pixels_kernel, dim3(NH * d->C), dim3(64), 0, st, p.V, gU, d->B, NH * d->C, d->HW);
+    }
     C2S_CHECK_LAUNCH("ltae_gU");
     if (g_emb != nullptr) {
         hipLaunchKernelGGL(gwc_kernel, dim3(NH * d->C), dim3(256), 0, st, g_emb, p.Z, gWc, d->B, d->C, d->HW);

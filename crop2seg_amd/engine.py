@@ -566,13 +566,15 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     p_eff = dropout_p if ctx.training else 0.0
     d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None, _ptr(seed_dev))
     attn = torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
-    attn_pre = torch.empty_like(attn) if ctx.tape is not None else None
+    attn_pre = torch.empty_like(attn)          # softmax before dropout (backward); score scratch of the streaming kernels
     emb = torch.empty(B, d_model, h, w, device=x5.device, dtype=torch.float32) if with_embedding else None
     stats = torch.empty(B * HW * n_head * 2, device=x5.device, dtype=torch.float32)
     Ud, s0d = U.detach(), s0.detach()
-    check(lib().c2s_ltae_attn_fwd(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
-                                  s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
-                                  attn.data_ptr(), _ptr(attn_pre), _ptr(emb), stats.data_ptr(), _stream()), "ltae_fwd")
+    fws = ctx.ws.get("ltae_fwd", lib().c2s_ltae_fwd_workspace_floats(C.byref(d)))
+    check(lib().c2s_ltae_attn_fwd_ws(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
+                                     s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
+                                     attn.data_ptr(), _ptr(attn_pre), _ptr(emb), stats.data_ptr(), fws.data_ptr(),
+                                     fws.numel(), _stream()), "ltae_fwd")
     if ctx.tape is None:
         return emb, attn
     tape = ctx.tape

@@ -222,6 +222,15 @@ typedef struct c2s_ltae_desc {
 int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                       const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
                       const int* valid, float* attn, float* attn_pre, float* emb, float* stats, void* stream);
+/* Same operation with a caller-provided workspace (c2s_ltae_fwd_workspace_floats): when the pixel count fills the chip
+ * with 64-pixel tiles (TimeUNet: L-TAE at full resolution) and C == 64 the streaming kernels are used (lane = pixel,
+ * 256-byte row segments, weights through the scalar cache); otherwise, or with workspace == NULL, the 16-pixel LDS
+ * kernel of c2s_ltae_attn_fwd. */
+size_t c2s_ltae_fwd_workspace_floats(const c2s_ltae_desc* d);
+int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
+                         const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
+                         const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
+                         float* workspace, size_t ws_floats, void* stream);
 size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
 /* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],
  * gU [16,C], gs0 [B,T,16], gWc [256,C] (embedding path only), gbc [256], ggamma [C], gbeta [C]. */

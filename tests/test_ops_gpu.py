@@ -210,6 +210,8 @@ def _ltae_state(C, g, flavour="tame"):
     (1, 5, 64, 8, True, False, True),
     (2, 7, 128, 4, False, True, True),
     (1, 61, 64, 16, True, True, False),     # TimeUNet-like: T = 61
+    (2, 5, 64, 128, True, True, True),      # 512 tiles of 64 pixels: the streaming kernels (TimeUNet resolution)
+    (2, 4, 64, 128, False, False, False),   # streaming, attention masks only
 ])
 def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     E, L = _engine()
