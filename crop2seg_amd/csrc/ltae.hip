@@ -559,6 +559,45 @@ __global__ __launch_bounds__(256) void gwc_kernel(const float* __restrict__ ge, 
     if (q == 0) gWc[(size_t)(h * DV + j) * C + c] = s;
 }
 
+// Large pixel counts: d Wc as 16 small GEMMs on the f32 MFMA (v_mfma_f32_16x16x4_f32), split over pixel slices.
+//   part[slice][16h+j][c] = sum_{pixels of the slice} ge[b,16h+j,pix] * Z[b,h,c,pix]        (C = 64)
+// Workgroup = (head, slice), 4 waves = the four 16-channel column tiles; the 16 ge rows and 64 Z rows of a 64-pixel
+// tile are staged row-major in LDS (row pitch 68 floats: A/B operand reads of the 64 lanes hit 64 distinct banks).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int GW_PITCH = 68;
+__global__ __launch_bounds__(256) void gwc_mfma_kernel(const float* __restrict__ ge, const float* __restrict__ Z,
+                                                       float* __restrict__ part, int B, int HW, int tiles_per_slice) {
+    constexpr int C = 64;
+    __shared__ float tl[(DV + C) * GW_PITCH];
+    const int h = blockIdx.x, slice = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tiles_per_b = HW / 64;
+    const int ntiles = B * tiles_per_b;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = slice * tiles_per_slice; tile < (slice + 1) * tiles_per_slice && tile < ntiles; ++tile) {
+        const int b = tile / tiles_per_b, pix0 = (tile % tiles_per_b) * 64;
+        __syncthreads();
+        // 80 rows x 16 float4
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int e = tid + i * 256;
+            const int row = e >> 4, q = e & 15;
+            const float* src = row < DV ? ge + ((size_t)b * NH * DV + h * DV + row) * HW
+                                        : Z + (((size_t)b * NH + h) * C + (row - DV)) * HW;
+            *reinterpret_cast<f32x4v*>(tl + row * GW_PITCH + 4 * q) = *reinterpret_cast<const f32x4v*>(src + pix0 + 4 * q);
+        }
+        __syncthreads();
+        const float* ap = tl + (lane & 15) * GW_PITCH + (lane >> 4);
+        const float* bp = tl + (DV + w * 16 + (lane & 15)) * GW_PITCH + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bp[4 * ks], acc, 0, 0, 0);
+    }
+    // D[row = 4*(lane>>4) + r][col = lane & 15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        part[((size_t)slice * NH * DV + h * DV + 4 * (lane >> 4) + r) * C + w * 16 + (lane & 15)] = acc[r];
+}
+
 // per-pixel GroupNorm over channel groups of a [B,C,HW] tensor (tae.py:437-440,488)
 __global__ void pixel_gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats,
@@ -680,14 +719,26 @@ __global__ void ltae_prep_kernel(const float* __restrict__ U, const float* __res
     }
 }
 
+#ifdef C2S_LT_STAMP
+// diagnostic build only: s_memtime at the phase boundaries of the streaming forward, per workgroup
+__device__ unsigned long long lt_stamps[4096 * 8];
+__device__ unsigned long long lt_stamps_bwd[4096 * 8];
+#define LT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lt_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LT_STAMP_B(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lt_stamps_bwd[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LT_STAMP(k)
+#define LT_STAMP_B(k)
+#endif
+
 template <int CPG>
 __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, const float* __restrict__ Ut,
                                                                 const float* __restrict__ cU) {
     constexpr int C = CPG * NH;
     __shared__ float st[NH][2][64];          // rstd, -mean*rstd per (group, pixel)
     __shared__ float asl[NH][64];            // sum_t attn per (head, pixel)
-    __shared__ float zh[C][64];              // one head's z
+    __shared__ float zh[4][C][64];           // z of four heads
     __shared__ float apl[NH][DV][64];        // sum_t attn * pe per (head, j, pixel)
+    __shared__ float ach[4 * 4 * 64 * 4];    // staged attention chunk of P4
     const int T = p.T, HW = p.HW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int tiles_per_b = (HW + 63) / 64;
@@ -698,22 +749,23 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const float* xb = p.x + (size_t)b * T * C * HW + pix;          // + (t*C + c)*HW
 
+    LT_STAMP(0);
     // ---- P1: GroupNorm statistics of group w (padded frames included, tae.py:461); shifted sums
     {
         const float* xg = xb + (size_t)(w * CPG) * HW;
         const float K0 = xg[0];
         float s = 0.f, ss = 0.f;
-        // 4 time steps x CPG channels per batch: >= 16 independent 256-byte loads in flight per wave
-        for (int t0 = 0; t0 < T; t0 += 4) {
-            float v[4][CPG];
+        // 8 time steps x CPG channels per batch: 32 independent 256-byte loads in flight per wave
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            float v[8][CPG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int t = t0 + u < T ? t0 + u : T - 1;
 #pragma unroll
                 for (int cc = 0; cc < CPG; ++cc) v[u][cc] = xg[(size_t)(t * C + cc) * HW];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 if (t0 + u < T) {
 #pragma unroll
                     for (int cc = 0; cc < CPG; ++cc) {
@@ -738,6 +790,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     }
     __syncthreads();
 
+    LT_STAMP(1);
     // ---- P2: scores of time steps t = w, w+16, ...   score[h] = s0 + cU[h] + sum_c Ut[c][h] * (x*rstd - mean*rstd)
     for (int t = w; t < T; t += NH) {
         float sc[NH];
@@ -745,20 +798,23 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
         for (int h = 0; h < NH; ++h) sc[h] = p.s0[(b * T + t) * NH + h] + cU[h];
         const float* xt = xb + (size_t)t * C * HW;
 #pragma unroll 1
-        for (int g0 = 0; g0 < NH; g0 += 4) {       // 4 groups = 16 loads in flight per wave (all 64 would not fit 128 registers)
-            float d[4][CPG];
+        for (int g0 = 0; g0 < NH; g0 += 8) {       // 8 groups = 32 loads in flight per wave (all 64 would not fit 128 registers)
+            float d[8][CPG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int cc = 0; cc < CPG; ++cc) d[u][cc] = xt[(size_t)((g0 + u) * CPG + cc) * HW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const float rs = st[g0 + u][0][lane], nm = st[g0 + u][1][lane];
 #pragma unroll
                 for (int cc = 0; cc < CPG; ++cc) {
                     const float dn = fmaf(d[u][cc], rs, nm);
 #pragma unroll
                     for (int h = 0; h < NH; ++h) sc[h] = fmaf(Ut[((g0 + u) * CPG + cc) * NH + h], dn, sc[h]);
+                    // one channel's 16 scalar operands at a time: hoisted together the 32 s_load_dwordx16 of the batch
+                    // overflow the SGPR file and come back through v_readlane (3 of them per FMA)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -772,6 +828,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     __threadfence_block();
     __syncthreads();
 
+    LT_STAMP(2);
     // ---- P3: softmax over T for head w, dropout; sum_t a and sum_t a*pe go to LDS for P5
     {
         float asum = 0.f, ape[DV];
@@ -817,6 +874,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     __threadfence_block();
     __syncthreads();
 
+    LT_STAMP(3);
     // ---- P4: z_raw[h][c] = sum_t attn[h,t] x[t,c] for the channels of group w (padded frames have attn == 0 exactly)
     float z[NH][CPG];
 #pragma unroll
@@ -824,19 +882,34 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
 #pragma unroll
         for (int cc = 0; cc < CPG; ++cc) z[h][cc] = 0.f;
     {
+        // attention of 4 time steps at a time through LDS ([t][h/4][pixel][4]: wave w stages head w, every wave reads all
+        // heads with ds_read_b128); with the 16 x loads of the chunk that is 20 requests in flight per wave
+        constexpr int ZCH = 4;
         const float* xg = xb + (size_t)(w * CPG) * HW;
-        const float* ab = p.attn + (size_t)b * T * HW + pix;          // + (h*B*T + t)*HW
-        for (int t = 0; t < T; ++t) {
-            if (p.valid != nullptr && p.valid[b * T + t] == 0) continue;
-            float xv[CPG], a[NH];
+        const float* aw = p.attn + (size_t)(w * p.B + b) * T * HW + pix;
+        for (int t0 = 0; t0 < T; t0 += ZCH) {
+            __syncthreads();
+            float xv[ZCH][CPG];
 #pragma unroll
-            for (int cc = 0; cc < CPG; ++cc) xv[cc] = xg[(size_t)(t * C + cc) * HW];
+            for (int tt = 0; tt < ZCH; ++tt) {
+                const int t = t0 + tt < T ? t0 + tt : T - 1;
+                ach[((tt * 4 + (w >> 2)) * 64 + lane) * 4 + (w & 3)] = t0 + tt < T ? aw[(size_t)t * HW] : 0.f;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) a[h] = ab[((size_t)h * p.B * T + t) * HW];
+                for (int cc = 0; cc < CPG; ++cc) xv[tt][cc] = xg[(size_t)(t * C + cc) * HW];
+            }
+            __syncthreads();
 #pragma unroll
-            for (int h = 0; h < NH; ++h)
+            for (int tt = 0; tt < ZCH; ++tt) {
 #pragma unroll
-                for (int cc = 0; cc < CPG; ++cc) z[h][cc] = fmaf(a[h], xv[cc], z[h][cc]);
+                for (int hq = 0; hq < 4; ++hq) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(ach + ((tt * 4 + hq) * 64 + lane) * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int cc = 0; cc < CPG; ++cc) z[hq * 4 + k][cc] = fmaf(a[k], xv[tt][cc], z[hq * 4 + k][cc]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     // GroupNorm affine of group w applied after the t-sum: z = A_c * z_raw + B_c * sum_t a
@@ -851,21 +924,29 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
         }
     }
 
-    // ---- P5: embedding, one head per round: emb[16h+j] = Wc[16h+j,:].z[h,:] + (sum_t a) bc[16h+j] + sum_t a pe_t[j]
-    for (int h = 0; h < NH; ++h) {
-        const float ah = asl[h][lane];
+    LT_STAMP(4);
+    // ---- P5: embedding, four heads per round: emb[16h+j] = Wc[16h+j,:].z[h,:] + (sum_t a) bc[16h+j] + sum_t a pe_t[j]
 #pragma unroll
-        for (int cc = 0; cc < CPG; ++cc) zh[w * CPG + cc][lane] = fmaf(Ac[cc], z[h][cc], Bc[cc] * ah);
+    for (int h0 = 0; h0 < NH; h0 += 4) {
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const float ah = asl[h0 + hh][lane];
+#pragma unroll
+            for (int cc = 0; cc < CPG; ++cc) zh[hh][w * CPG + cc][lane] = fmaf(Ac[cc], z[h0 + hh][cc], Bc[cc] * ah);
+        }
         __syncthreads();
-        {
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const int h = h0 + hh;
             const float* wr = p.Wc + (size_t)(h * DV + w) * C;
-            float o = fmaf(ah, p.bc[h * DV + w], apl[h][w][lane]);
+            float o = fmaf(asl[h][lane], p.bc[h * DV + w], apl[h][w][lane]);
 #pragma unroll 16
-            for (int c = 0; c < C; ++c) o = fmaf(wr[c], zh[c][lane], o);
+            for (int c = 0; c < C; ++c) o = fmaf(wr[c], zh[hh][c][lane], o);
             if (act) p.emb[((size_t)b * NH * DV + h * DV + w) * HW + pix] = o;
         }
         __syncthreads();
     }
+    LT_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------ streaming backward
@@ -897,22 +978,28 @@ __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 l
     return v;
 }
 
-// stage attn and gs of time steps [t0, t0+SCH) for the tile's pixels: LDS [arr 2][SCH][h/4][32 px][4]
-__device__ __forceinline__ void stage_heads_chunk(const LtaeParams& p, float* buf, int b, int pix, int t0, int w, int px, int hf,
-                                                  const float* gs_src) {
-    // 2 arrays x SCH x 16 heads = 128 rows of 32 pixels; wave w loads rows [8w, 8w+8): 4 per half
+// attn and gs of time steps [t0, t0+SCH) for the tile's pixels, staged as LDS [arr 2][SCH][h/4][32 px][4]:
+// 2 arrays x SCH x 16 heads = 128 rows of 32 pixels; wave w owns rows [8w, 8w+8), 4 per half.  Split into the global
+// loads (issued a chunk ahead, under the previous chunk's arithmetic) and the LDS writes.
+__device__ __forceinline__ void chunk_load(const LtaeParams& p, float (&v)[4], int b, int pix, int t0, int w, int hf,
+                                           const float* gs_src) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = w * 8 + hf * 4 + i;
         const int arr = row >> 6, rem = row & 63;
         const int tt = rem >> 4, h = rem & 15;
-        const int t = t0 + tt;
-        float v = 0.f;
-        if (t < p.T) {
-            const size_t o = ((size_t)(h * p.B + b) * p.T + t) * p.HW + pix;
-            v = arr == 0 ? p.attn_in[o] : gs_src[o];
-        }
-        buf[(((arr * SCH + tt) * 4 + (h >> 2)) * SPT + px) * 4 + (h & 3)] = v;
+        const int t = t0 + tt < p.T ? t0 + tt : p.T - 1;
+        const size_t o = ((size_t)(h * p.B + b) * p.T + t) * p.HW + pix;
+        v[i] = arr == 0 ? p.attn_in[o] : gs_src[o];
+    }
+}
+__device__ __forceinline__ void chunk_store(float* buf, const float (&v)[4], int w, int px, int hf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w * 8 + hf * 4 + i;
+        const int arr = row >> 6, rem = row & 63;
+        const int tt = rem >> 4, h = rem & 15;
+        buf[(((arr * SCH + tt) * 4 + (h >> 2)) * SPT + px) * 4 + (h & 3)] = v[i];
     }
 }
 
@@ -937,6 +1024,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const float* xb = p.x + (size_t)b * T * C * HW + pix;
 
+    LT_STAMP_B(0);
     // ---- S1: wave = head
     {
         const int h = w;
@@ -964,13 +1052,26 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
 #pragma unroll
         for (int j = 0; j < DV; ++j) gebc = fmaf(ge[j], p.bc[h * DV + j], gebc);
         float asum = 0.f;
-        for (int t = hf; t < T; t += 2) {
-            const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
-            float c0 = gebc + (p.g_attn != nullptr ? p.g_attn[o] : 0.f);
+        for (int i0 = 0; i0 < 32; i0 += 8) {           // t = 2i + hf, 8 time steps per batch of loads
+            float av[8], gv[8];
 #pragma unroll
-            for (int j = 0; j < DV; ++j) c0 = fmaf(ge[j], p.pe[(b * T + t) * DV + j], c0);
-            asum += p.attn_in[o];
-            if (act) p.GS[o] = c0;
+            for (int u = 0; u < 8; ++u) {
+                const int t = 2 * (i0 + u) + hf < T ? 2 * (i0 + u) + hf : T - 1;
+                const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix;
+                av[u] = p.attn_in[o];
+                gv[u] = p.g_attn != nullptr ? p.g_attn[o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = 2 * (i0 + u) + hf;
+                if (t < T) {
+                    float c0 = gebc + gv[u];
+#pragma unroll
+                    for (int j = 0; j < DV; ++j) c0 = fmaf(ge[j], p.pe[(b * T + t) * DV + j], c0);
+                    asum += av[u];
+                    if (act) p.GS[((size_t)(h * p.B + b) * T + t) * HW + pix] = c0;
+                }
+            }
         }
         asum += __shfl_xor(asum, 32, 64);
         if (hf == 0) asl[h * SPT + px] = asum;
@@ -988,6 +1089,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
     __threadfence_block();
     __syncthreads();
 
+    LT_STAMP_B(1);
     // ---- A: wave = time steps t = w, w+16, ...; half = channels [32 hf, 32 hf + 32)
     for (int t = w; t < T; t += NH) {
         const float* xt = xb + (size_t)(t * C + hf * (C / 2)) * HW;
@@ -1020,20 +1122,34 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
     __threadfence_block();
     __syncthreads();
 
+    LT_STAMP_B(2);
     // ---- B: wave = head; half = t parity
     {
         const int h = w;
         const size_t o0 = (size_t)(h * p.B + b) * T * HW + pix;
+        // all a' and ga of this (pixel, head, t parity) in registers: one round of loads instead of 31 dependent ones
+        float ap[32], ga[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int t = 2 * i + hf < T ? 2 * i + hf : T - 1;
+            ap[i] = p.attn_pre_in[o0 + (size_t)t * HW];
+            ga[i] = p.GS[o0 + (size_t)t * HW];
+        }
         float dsum = 0.f;
-        for (int t = hf; t < T; t += 2) dsum = fmaf(p.attn_pre_in[o0 + (size_t)t * HW], p.GS[o0 + (size_t)t * HW], dsum);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) dsum = 2 * i + hf < T ? fmaf(ap[i], ga[i], dsum) : dsum;
         dsum += __shfl_xor(dsum, 32, 64);
         float gssum = 0.f;
-        for (int t = hf; t < T; t += 2) {
-            const float gs = p.attn_pre_in[o0 + (size_t)t * HW] * (p.GS[o0 + (size_t)t * HW] - dsum);
-            if (act) p.GS[o0 + (size_t)t * HW] = gs;
-            gssum += gs;
-            const float r = half_sum32(act ? gs : 0.f);            // d s0[b,t,h]: sum over the pixels of the tile
-            if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + h] = r;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int t = 2 * i + hf;
+            if (t < T) {
+                const float gs = ap[i] * (ga[i] - dsum);
+                if (act) p.GS[o0 + (size_t)t * HW] = gs;
+                gssum += gs;
+                const float r = half_sum32(act ? gs : 0.f);            // d s0[b,t,h]: sum over the pixels of the tile
+                if (px == 0) p.part_s0[((size_t)blockIdx.x * T + t) * NH + h] = r;
+            }
         }
         gssum += __shfl_xor(gssum, 32, 64);
         if (hf == 0) gsl[h * SPT + px] = gssum;
@@ -1041,6 +1157,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
     __threadfence_block();
     __syncthreads();
 
+    LT_STAMP_B(3);
     // ---- C: wave = group g; half = channel pair (c0, c0+1) = 4g + 2hf
     {
         const int g = w, c0 = g * CPG + 2 * hf;
@@ -1048,17 +1165,26 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
 #pragma unroll
         for (int h = 0; h < NH; ++h) { Vr[h][0] = Vr[h][1] = Zr[h][0] = Zr[h][1] = 0.f; }
         const float* xg = xb + (size_t)c0 * HW;
-        for (int t0 = 0; t0 < T; t0 += SCH) {
-            __syncthreads();                                     // previous chunk consumed
-            stage_heads_chunk(p, chk, b, pix, t0, w, px, hf, p.GS);
-            float xv[SCH][2];
+        float sv[4], xn[SCH][2];
+        auto issue = [&](int t0) {                               // global loads of one chunk -> registers
+            chunk_load(p, sv, b, pix, t0, w, hf, p.GS);
 #pragma unroll
             for (int tt = 0; tt < SCH; ++tt) {
                 const int t = t0 + tt < T ? t0 + tt : T - 1;
-                xv[tt][0] = xg[(size_t)(t * C) * HW];
-                xv[tt][1] = xg[(size_t)(t * C + 1) * HW];
+                xn[tt][0] = xg[(size_t)(t * C) * HW];
+                xn[tt][1] = xg[(size_t)(t * C + 1) * HW];
             }
+        };
+        issue(0);
+        for (int t0 = 0; t0 < T; t0 += SCH) {
+            __syncthreads();                                     // previous chunk consumed
+            chunk_store(chk, sv, w, px, hf);
+            float xv[SCH][2];
+#pragma unroll
+            for (int tt = 0; tt < SCH; ++tt) { xv[tt][0] = xn[tt][0]; xv[tt][1] = xn[tt][1]; }
             __syncthreads();
+            if (t0 + SCH < T) issue(t0 + SCH);                   // in flight during this chunk's arithmetic (after the barrier:
+                                                                 // __syncthreads() waits for outstanding loads)
 #pragma unroll
             for (int tt = 0; tt < SCH; ++tt) {
                 if (t0 + tt < T) {
@@ -1128,6 +1254,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
             sb.M[(pidx * NH + g) * 2 + 1] = m2 * inv_n;
         }
     }
+    LT_STAMP_B(4);
     __syncthreads();
     // d U partial of the tile: thread = (head, channel), fixed-order sum over the 32 pixels (rotated start: no bank conflicts)
     {
@@ -1138,6 +1265,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
         for (int i = 0; i < SPT; ++i) sum += vp[((i + (c >> 2)) & (SPT - 1)) * 4];
         sb.part_U[((size_t)blockIdx.x * NH + h) * C + c] = sum;
     }
+    LT_STAMP_B(5);
 }
 
 template <int CPG>
@@ -1188,17 +1316,25 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, 
     const float gm0 = (hf ? p.gamma[g * CPG + 2] : p.gamma[g * CPG]) * rstd, gm1 = (hf ? p.gamma[g * CPG + 3] : p.gamma[g * CPG + 1]) * rstd;
     const float* xg = p.x + (size_t)b * T * C * HW + (size_t)c0 * HW + pix;
     float* gxg = p.gx + (size_t)b * T * C * HW + (size_t)c0 * HW + pix;
-    for (int t0 = 0; t0 < T; t0 += SCH) {
-        __syncthreads();
-        stage_heads_chunk(p, chk, b, pix, t0, w, px, hf, p.GS);
-        float xv[SCH][2];
+    float sv[4], xn[SCH][2];
+    auto issue = [&](int t0) {
+        chunk_load(p, sv, b, pix, t0, w, hf, p.GS);
 #pragma unroll
         for (int tt = 0; tt < SCH; ++tt) {
             const int t = t0 + tt < T ? t0 + tt : T - 1;
-            xv[tt][0] = xg[(size_t)(t * C) * HW];
-            xv[tt][1] = xg[(size_t)(t * C + 1) * HW];
+            xn[tt][0] = xg[(size_t)(t * C) * HW];
+            xn[tt][1] = xg[(size_t)(t * C + 1) * HW];
         }
+    };
+    issue(0);
+    for (int t0 = 0; t0 < T; t0 += SCH) {
         __syncthreads();
+        chunk_store(chk, sv, w, px, hf);
+        float xv[SCH][2];
+#pragma unroll
+        for (int tt = 0; tt < SCH; ++tt) { xv[tt][0] = xn[tt][0]; xv[tt][1] = xn[tt][1]; }
+        __syncthreads();
+        if (t0 + SCH < T) issue(t0 + SCH);
 #pragma unroll
         for (int tt = 0; tt < SCH; ++tt) {
             const int t = t0 + tt;
@@ -1257,6 +1393,15 @@ void fill(LtaeParams& p, const c2s_ltae_desc* d) {
 }
 
 }  // namespace
+
+#ifdef C2S_LT_STAMP
+extern "C" int c2s_debug_ltae_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lt_stamps), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : 1;
+}
+extern "C" int c2s_debug_ltae_stamps_bwd(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lt_stamps_bwd), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t c2s_ltae_fwd_workspace_floats(const c2s_ltae_desc* d) {
     if (!d) return 0;
@@ -1398,7 +1543,18 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         hipLaunchKernelGGL(sum_over_pixels_kernel, dim3(NH * d->C), dim3(64), 0, st, p.V, gU, d->B, NH * d->C, d->HW);
     }
     C2S_CHECK_LAUNCH("ltae_gU");
-    if (g_emb != nullptr) {
+    if (g_emb != nullptr && stream_path && d->HW % 64 == 0) {
+        // 32 pixel slices per head; the partials live behind part_U in the (unused) V area of the workspace
+        const int ntiles = d->B * (d->HW / 64);
+        const int slices = ntiles >= 32 ? 32 : ntiles;
+        const int tps = (ntiles + slices - 1) / slices;
+        float* part_wc = sb.part_U + tiles * NH * d->C;
+        hipLaunchKernelGGL(gwc_mfma_kernel, dim3(NH, slices), dim3(256), 0, st, g_emb, p.Z, part_wc, d->B, d->HW, tps);
+        C2S_CHECK_LAUNCH("ltae_gWc_mfma");
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(NH * DV * d->C), dim3(64), 0, st, part_wc, gWc, slices, NH * DV * d->C,
+                           (long)NH * DV * d->C);
+        C2S_CHECK_LAUNCH("ltae_gWc_reduce");
+    } else if (g_emb != nullptr) {
         hipLaunchKernelGGL(gwc_kernel, dim3(NH * d->C), dim3(256), 0, st, g_emb, p.Z, gWc, d->B, d->C, d->HW);
         C2S_CHECK_LAUNCH("ltae_gWc");
     } else {
