@@ -15,6 +15,7 @@
 // Reference call sites replaced: convolution_backward-weight of src/backbones/conv.py:70-80,263-271,
 // 378-390.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -425,6 +426,265 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(WgradParams p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 pad-1 weight gradient as Winograd F(2x2,3x3):  d U[xi][nu][cin][cout] = sum_{2x2 blocks} V * Mt  with
+// V = Bt d B (4x4 input patch) and Mt = A gy At (2x2 output-gradient block -> 4x4), then d W = Gt (d U) G in the
+// reduce kernel: 16 multiplies per (block, channel pair) instead of 36.
+// MFMA: D[cin][cout] per transform point, A operand = V (rows = cin, k = block), B operand = Mt (cols = cout).
+// Workgroup = 4 waves, wave xi owns row xi of the transform domain: 4 nu x 2 cout fragments = 8 accumulators for a
+// (32 cin x 64 cout) block.  A spatial tile is 2 x 16 blocks (4 x 32 output pixels): 16 k-steps of 2 blocks.  Both
+// operands are transformed on the fly by the lane that feeds them (its channel's patch rows / gradient block come as
+// ds_read_b64 from channel-major LDS tiles whose pitch is 2*odd mod 64 banks: conflict-free).  The next tile is
+// prefetched into registers under the MFMA loop (single LDS buffer, two barriers per tile), as in the direct kernel.
+constexpr int WW_XP = 206;     // raw input tile pitch per channel: 6 x 34 = 204 -> 206 (= 2*7 mod 64)
+constexpr int WW_GP = 130;     // gout tile pitch per channel:      4 x 32 = 128 -> 130 (= 2*1 mod 64)
+
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams p) {
+    constexpr int XR = 6, XC = 34;
+    constexpr int NXI = 32 * XR * 8;               // interior float4 items of the raw tile
+    constexpr int NXH = 2 * 32 * XR;               // halo scalars
+    constexpr int NG = 64 * 4 * 8;                 // gout float4 items
+    constexpr int XI_PT = NXI / 256, XH_PT = (NXH + 255) / 256, G_PT = NG / 256;
+    extern __shared__ float lds[];
+    float* Xl = lds;                               // [32 cin][WW_XP]
+    float* Gl = lds + 32 * WW_XP;                  // [64 cout][WW_GP]
+
+    const int tid = threadIdx.x, lane = tid & 63, xi = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int cb = blockIdx.y * 32, ob = blockIdx.z * 64;
+    const int slice = blockIdx.x;
+    const int Cin = p.C0 + p.C1;
+    const int HW = p.Hin * p.Win;
+    const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
+    // rows of Bt (input) and of A (output gradient) combined by this wave
+    const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sb_ = xi == 1 ? 1.f : -1.f;                        // t = d[ra] + sb * d[rb]
+    const float ga = xi == 3 ? 0.f : 1.f, gb = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);   // r = ga * gy[0] + gb * gy[1]
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][m][r] = 0.f;
+
+    f32x4 xi4[XI_PT];
+    float xh[XH_PT];
+    f32x4 gv[G_PT];
+    auto prefetch = [&](int tile) {
+        const int n = tile / (p.tiles_x * p.tiles_y);
+        const int trem = tile - n * (p.tiles_x * p.tiles_y);
+        const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+        const int oy0 = tyi * 4, ox0 = txi * 32;
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
+        const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
+#pragma unroll
+        for (int i = 0; i < XI_PT; ++i) {
+            const int e = tid + i * 256;
+            const int j = e & 7, rr = e >> 3;
+            const int c = rr & 31, r = rr >> 5;
+            int gy = oy0 - 1 + r;
+            bool ok = true;
+            if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
+            const int cg = cb + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && cg < Cin) {
+                const float* sp = cg < p.C0 ? s0n + (size_t)cg * HW : s1n + (size_t)(cg - p.C0) * HW;
+                v = *reinterpret_cast<const f32x4*>(sp + (size_t)gy * p.Win + ox0 + 4 * j);
+            }
+            xi4[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XH_PT; ++i) {
+            const int e = tid + i * 256;
+            float v = 0.f;
+            if (e < NXH) {
+                const int side = e & 1, rr = e >> 1;
+                const int c = rr & 31, r = rr >> 5;
+                int gy = oy0 - 1 + r;
+                int gx = side == 0 ? ox0 - 1 : ox0 + 32;
+                bool ok = true;
+                if (reflect) { gy = reflect_idx(gy, p.Hin); gx = reflect_idx(gx, p.Win); }
+                else ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const int cg = cb + c;
+                if (ok && cg < Cin) {
+                    const float* sp = cg < p.C0 ? s0n + (size_t)cg * HW : s1n + (size_t)(cg - p.C0) * HW;
+                    v = sp[(size_t)gy * p.Win + gx];
+                }
+            }
+            xh[i] = v;
+        }
+        const float* gn = p.gout + (size_t)n * p.Cout * HW;
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int e = tid + i * 256;
+            const int j = e & 7, rr = e >> 3;
+            const int o = rr & 63, r = rr >> 6;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ob + o < p.Cout) v = *reinterpret_cast<const f32x4*>(gn + (size_t)(ob + o) * HW + (size_t)(oy0 + r) * p.Win + ox0 + 4 * j);
+            gv[i] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < XI_PT; ++i) {
+            const int e = tid + i * 256;
+            const int j = e & 7, rr = e >> 3;
+            const int c = rr & 31, r = rr >> 5;
+            float* d = Xl + c * WW_XP + r * XC + 1 + 4 * j;
+            d[0] = xi4[i].x; d[1] = xi4[i].y; d[2] = xi4[i].z; d[3] = xi4[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < XH_PT; ++i) {
+            const int e = tid + i * 256;
+            if (e < NXH) {
+                const int side = e & 1, rr = e >> 1;
+                const int c = rr & 31, r = rr >> 5;
+                Xl[c * WW_XP + r * XC + (side == 0 ? 0 : XC - 1)] = xh[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int e = tid + i * 256;
+            const int j = e & 7, rr = e >> 3;
+            const int o = rr & 63, r = rr >> 6;
+            // the pitch keeps rows 8-byte (not 16-byte) aligned: two ds_write_b64
+            f32x2w* gd = reinterpret_cast<f32x2w*>(Gl + o * WW_GP + r * 32 + 4 * j);
+            gd[0] = f32x2w{gv[i].x, gv[i].y};
+            gd[1] = f32x2w{gv[i].z, gv[i].w};
+        }
+    };
+    auto next_tile = [&](int tile) {
+        while (tile < p.ntiles) {
+            const int n = tile / (p.tiles_x * p.tiles_y);
+            if (p.valid == nullptr || p.valid[n] != 0) break;
+            tile += p.nslices;
+        }
+        return tile;
+    };
+
+    // operands of k-step kk: blocks t = 2*kk + lk of the 2 x 16 block tile
+    auto load_ops = [&](int kk, f32x2w (&d)[4], f32x2w (&g)[2][2]) {
+        const int t = 2 * kk + lk;
+        const int by = t >> 4, bx = t & 15;
+        const float* pa = Xl + li * WW_XP + (2 * by + ra) * XC + 2 * bx;
+        const float* pb = Xl + li * WW_XP + (2 * by + rb) * XC + 2 * bx;
+        d[0] = *reinterpret_cast<const f32x2w*>(pa);
+        d[1] = *reinterpret_cast<const f32x2w*>(pa + 2);
+        d[2] = *reinterpret_cast<const f32x2w*>(pb);
+        d[3] = *reinterpret_cast<const f32x2w*>(pb + 2);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float* pg = Gl + (m * 32 + li) * WW_GP + (2 * by) * 32 + 2 * bx;
+            g[m][0] = *reinterpret_cast<const f32x2w*>(pg);
+            g[m][1] = *reinterpret_cast<const f32x2w*>(pg + 32);
+        }
+    };
+
+    int tile = next_tile(slice);
+    if (tile < p.ntiles) prefetch(tile);
+    while (tile < p.ntiles) {
+        commit();
+        __syncthreads();
+        const int nxt = next_tile(tile + p.nslices);
+        if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
+        f32x2w d[2][4], g[2][2][2];
+        load_ops(0, d[0], g[0]);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const f32x2w(&dd)[4] = d[kk & 1];
+            const f32x2w(&gg)[2][2] = g[kk & 1];
+            // input transform (row pair of Bt, then the four columns)
+            const float t0 = fmaf(sb_, dd[2].x, dd[0].x), t1 = fmaf(sb_, dd[2].y, dd[0].y);
+            const float t2 = fmaf(sb_, dd[3].x, dd[1].x), t3 = fmaf(sb_, dd[3].y, dd[1].y);
+            const float V[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+            // output-gradient transform (row of A, then the four columns of At)
+            float Mt[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float r0 = fmaf(gb, gg[m][1].x, ga * gg[m][0].x), r1 = fmaf(gb, gg[m][1].y, ga * gg[m][0].y);
+                Mt[m][0] = r0; Mt[m][1] = r0 + r1; Mt[m][2] = r0 - r1; Mt[m][3] = -r1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0], Mt[0][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < 16) load_ops(kk + 1, d[(kk + 1) & 1], g[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (v + m > 0) acc[v][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v], Mt[m][v], acc[v][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        tile = nxt;
+    }
+
+    // ---- slab [slice][xi*4+nu][CinP][CoutB]
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float* sl = p.slabs + (((size_t)slice * 16 + xi * 4 + v) * p.CinP + cb) * p.CoutB + ob + m * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                sl[(size_t)ci * p.CoutB] = acc[v][m][r];
+            }
+        }
+}
+
+struct TapTable9w {
+    int off[9];
+};
+
+// d W[o][c][ky][kx] = (Gt dU G)[ky][kx] from the slice-summed dU [16][Cin][Cout]; one thread per (c, o)
+__global__ void wgrad_winograd_transform_kernel(const float* __restrict__ dU, float* __restrict__ dst, int Cin, int Cout,
+                                                long so, long sc, TapTable9w tt, int accumulate) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= (long)Cin * Cout) return;
+    const int o = (int)(e % Cout), c = (int)(e / Cout);
+    float u[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) u[q] = dU[((size_t)q * Cin + c) * Cout + o];
+    // t = Gt u (3x4), then w = t G (3x3);  Gt = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = u[0 * 4 + j] + 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]);
+        t[1][j] = 0.5f * (u[1 * 4 + j] - u[2 * 4 + j]);
+        t[2][j] = 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]) + u[3 * 4 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float w0 = t[i][0] + 0.5f * (t[i][1] + t[i][2]);
+        const float w1 = 0.5f * (t[i][1] - t[i][2]);
+        const float w2 = 0.5f * (t[i][1] + t[i][2]) + t[i][3];
+        float* d0 = dst + o * so + c * sc + tt.off[i * 3 + 0];
+        float* d1 = dst + o * so + c * sc + tt.off[i * 3 + 1];
+        float* d2 = dst + o * so + c * sc + tt.off[i * 3 + 2];
+        *d0 = accumulate ? *d0 + w0 : w0;
+        *d1 = accumulate ? *d1 + w1 : w1;
+        *d2 = accumulate ? *d2 + w2 : w2;
+    }
+}
+
+// Winograd path: wide 3x3 layers on planes that tile into 4 x 32 pixel pieces (C2S_WINOGRAD=0 disables it)
+bool wino_wgrad(const c2s_wgrad_desc* d) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("C2S_WINOGRAD");
+        enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return enabled && d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1 && d->C0 + d->C1 >= 32 &&
+           d->Cout >= 32 && d->Win == d->Wout && d->Hin == d->Hout && d->Wout % 32 == 0 && d->Hout % 4 == 0;
+}
+
 struct TapTable {
     int off[16];
 };
@@ -530,6 +790,7 @@ int check(const c2s_wgrad_desc* d) {
 extern "C" size_t c2s_wgrad_workspace_floats(const c2s_wgrad_desc* d) {
     if (!d) return 0;
     const size_t CinP = (size_t)cdiv(d->C0 + d->C1, 32) * 32, CoutB = (size_t)cdiv(d->Cout, 64) * 64;
+    if (wino_wgrad(d)) return ((size_t)d->nslices + 1) * 16 * CinP * CoutB;      // slabs + the slice-summed dU
     return (size_t)d->nslices * d->KH * d->KW * CinP * CoutB;
 }
 
@@ -546,6 +807,17 @@ extern "C" int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const 
     p.CinP = cdiv(d->C0 + d->C1, 32) * 32;
     p.CoutB = cdiv(d->Cout, 64) * 64;
     hipStream_t st = (hipStream_t)stream;
+    if (wino_wgrad(d)) {
+        p.tiles_x = d->Wout / 32;
+        p.tiles_y = d->Hout / 4;
+        p.ntiles = d->N * p.tiles_x * p.tiles_y;
+        p.log2pc = 5;
+        const size_t ldsb = ((size_t)32 * WW_XP + (size_t)64 * WW_GP) * sizeof(float);
+        dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
+        hipLaunchKernelGGL(conv_wgrad_winograd_kernel, grid, dim3(256), ldsb, st, p);
+        C2S_CHECK_LAUNCH("conv_wgrad_winograd");
+        return C2S_OK;
+    }
     if (d->KH == 3 && d->S == 1) return launch_wgrad<3, 1>(d, p, st);
     if (d->KH == 1 && d->S == 1) return launch_wgrad<1, 1>(d, p, st);
     if (d->KH == 4 && d->S == 2) return launch_wgrad<4, 2>(d, p, st);
@@ -558,9 +830,28 @@ extern "C" int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, flo
     if (int rc = check(d)) return rc;
     C2S_REQUIRE(slabs && dst && host_tap_off, "wgrad_reduce: null pointer");
     const int NT = d->KH * d->KW;
+    const int Cin = d->C0 + d->C1;
+    if (wino_wgrad(d)) {
+        // (1) slice sum of the 16 transform points with the generic reduce kernel (fixed order) into dU [16][Cin][Cout]
+        //     stored behind the slabs, (2) dW = Gt dU G
+        const int CinP = cdiv(Cin, 32) * 32, CoutB = cdiv(d->Cout, 64) * 64;
+        float* dU = const_cast<float*>(slabs) + (size_t)d->nslices * 16 * CinP * CoutB;
+        TapTable t16;
+        for (int i = 0; i < 16; ++i) t16.off[i] = i * Cin * d->Cout;
+        const long tot16 = (long)16 * Cin * d->Cout;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(tot16, 256)), dim3(256), 0, (hipStream_t)stream, slabs, dU,
+                           d->nslices, 16, Cin, d->Cout, CinP, CoutB, 1L, (long)d->Cout, t16, 0);
+        C2S_CHECK_LAUNCH("wgrad_winograd_slice_sum");
+        TapTable9w t9;
+        for (int i = 0; i < 9; ++i) t9.off[i] = host_tap_off[i];
+        const long tot = (long)Cin * d->Cout;
+        hipLaunchKernelGGL(wgrad_winograd_transform_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, dU, dst,
+                           Cin, d->Cout, stride_o, stride_c, t9, accumulate);
+        C2S_CHECK_LAUNCH("wgrad_winograd_transform");
+        return C2S_OK;
+    }
     TapTable tt;
     for (int i = 0; i < 16; ++i) tt.off[i] = i < NT ? host_tap_off[i] : 0;
-    const int Cin = d->C0 + d->C1;
     const long total = (long)NT * Cin * d->Cout;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, slabs, dst,
                        d->nslices, NT, Cin, d->Cout, cdiv(Cin, 32) * 32, cdiv(d->Cout, 64) * 64, stride_o, stride_c, tt,
