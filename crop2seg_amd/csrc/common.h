@@ -45,11 +45,17 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * n - 2 - i : i;
 }
 
-// counter-based RNG (splitmix64 finaliser of key ^ index): uniform in [0,1)
+// counter-based RNG: two rounds of a 32-bit avalanche hash (multiply / xor-shift) over (index, key): uniform in [0,1).
+// 14 integer VALU ops per draw (a 64-bit splitmix finaliser costs ~30 on this ISA: no 64-bit multiplier) -- the L-TAE
+// kernels draw one number per attention element, 976 per pixel at T = 61.
+__device__ __forceinline__ uint32_t c2s_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ float c2s_uniform(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+    uint32_t h = c2s_hash32((uint32_t)idx ^ (uint32_t)seed);
+    h = c2s_hash32(h ^ (uint32_t)(idx >> 32) * 0x9E3779B9u ^ (uint32_t)(seed >> 32));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
 }

@@ -736,9 +736,10 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     constexpr int C = CPG * NH;
     __shared__ float st[NH][2][64];          // rstd, -mean*rstd per (group, pixel)
     __shared__ float asl[NH][64];            // sum_t attn per (head, pixel)
-    __shared__ float zh[4][C][64];           // z of four heads
     __shared__ float apl[NH][DV][64];        // sum_t attn * pe per (head, j, pixel)
-    __shared__ float ach[4 * 4 * 64 * 4];    // staged attention chunk of P4
+    constexpr int ZP = 65;                   // pitch of a z row: the MFMA B-operand reads (16 pixels x channels 16k+ks) hit 64 banks
+    __shared__ float zu[4 * C * ZP];         // P4: staged attention chunk [4 t][4][64][4]; P5: z of four heads [4][C][ZP]
+    float* ach = zu;
     const int T = p.T, HW = p.HW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int tiles_per_b = (HW + 63) / 64;
@@ -884,20 +885,31 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     {
         // attention of 4 time steps at a time through LDS ([t][h/4][pixel][4]: wave w stages head w, every wave reads all
         // heads with ds_read_b128); with the 16 x loads of the chunk that is 20 requests in flight per wave
-        constexpr int ZCH = 4;
+        constexpr int ZCH = 2;
         const float* xg = xb + (size_t)(w * CPG) * HW;
         const float* aw = p.attn + (size_t)(w * p.B + b) * T * HW + pix;
+        float an[ZCH], xn[ZCH][CPG];
+        auto issue = [&](int t0) {                 // global loads of one chunk -> registers
+#pragma unroll
+            for (int tt = 0; tt < ZCH; ++tt) {
+                const int t = t0 + tt < T ? t0 + tt : T - 1;
+                an[tt] = aw[(size_t)t * HW];
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) xn[tt][cc] = xg[(size_t)(t * C + cc) * HW];
+            }
+        };
+        issue(0);
         for (int t0 = 0; t0 < T; t0 += ZCH) {
             __syncthreads();
             float xv[ZCH][CPG];
 #pragma unroll
             for (int tt = 0; tt < ZCH; ++tt) {
-                const int t = t0 + tt < T ? t0 + tt : T - 1;
-                ach[((tt * 4 + (w >> 2)) * 64 + lane) * 4 + (w & 3)] = t0 + tt < T ? aw[(size_t)t * HW] : 0.f;
+                ach[((tt * 4 + (w >> 2)) * 64 + lane) * 4 + (w & 3)] = t0 + tt < T ? an[tt] : 0.f;
 #pragma unroll
-                for (int cc = 0; cc < CPG; ++cc) xv[tt][cc] = xg[(size_t)(t * C + cc) * HW];
+                for (int cc = 0; cc < CPG; ++cc) xv[tt][cc] = xn[tt][cc];
             }
             __syncthreads();
+            if (t0 + ZCH < T) issue(t0 + ZCH);     // in flight during this chunk's arithmetic (after the barrier: it drains loads)
 #pragma unroll
             for (int tt = 0; tt < ZCH; ++tt) {
 #pragma unroll
@@ -925,26 +937,43 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     }
 
     LT_STAMP(4);
-    // ---- P5: embedding, four heads per round: emb[16h+j] = Wc[16h+j,:].z[h,:] + (sum_t a) bc[16h+j] + sum_t a pe_t[j]
+    // ---- P5: embedding on the MFMA (v_mfma_f32_16x16x4_f32), four heads per round:
+    //   emb[16h+j][px] = sum_c Wc[16h+j][c] z[h][c][px] + (sum_t a) bc[16h+j] + sum_t a pe_t[j]
+    // z of the round goes to LDS as [head][c][pixel]; wave w multiplies head w>>2 of the round by the 16-pixel tile w&3:
+    // A = Wc rows (i = j, k = channel), B = z (k = channel, n = pixel), 16 k-steps.
+    const int mi = lane & 15, mk = lane >> 4;
 #pragma unroll
     for (int h0 = 0; h0 < NH; h0 += 4) {
+        __syncthreads();                           // previous round (or the last P4 chunk) consumed
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
             const float ah = asl[h0 + hh][lane];
 #pragma unroll
-            for (int cc = 0; cc < CPG; ++cc) zh[hh][w * CPG + cc][lane] = fmaf(Ac[cc], z[h0 + hh][cc], Bc[cc] * ah);
+            for (int cc = 0; cc < CPG; ++cc) zu[(hh * C + w * CPG + cc) * ZP + lane] = fmaf(Ac[cc], z[h0 + hh][cc], Bc[cc] * ah);
         }
         __syncthreads();
+        if (h0 == 0) LT_STAMP(6);
+        const int h = h0 + (w >> 2), nt = w & 3;
+        // MFMA k index <-> channel c = 16*mk + ks: lane (j, mk) needs 16 consecutive weights = 4 float4 loads
+        const f32x4* wa = reinterpret_cast<const f32x4*>(p.Wc + (size_t)(h * DV + mi) * C + 16 * mk);
+        const float* zb = zu + ((w >> 2) * C + 16 * mk) * ZP + nt * 16 + mi;
+        f32x4 wv[4];
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            const int h = h0 + hh;
-            const float* wr = p.Wc + (size_t)(h * DV + w) * C;
-            float o = fmaf(asl[h][lane], p.bc[h * DV + w], apl[h][w][lane]);
-#pragma unroll 16
-            for (int c = 0; c < C; ++c) o = fmaf(wr[c], zh[hh][c][lane], o);
-            if (act) p.emb[((size_t)b * NH * DV + h * DV + w) * HW + pix] = o;
+        for (int i = 0; i < 4; ++i) wv[i] = wa[i];
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks >> 2][ks & 3], zb[ks * ZP], d, 0, 0, 0);
+        if (h0 == 0) LT_STAMP(7);
+        // D[row j = 4*mk + r][col = pixel nt*16 + mi]
+        const int pl = nt * 16 + mi;
+        if (pix0 + pl < HW) {
+            const float ah = asl[h][pl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * mk + r;
+                p.emb[((size_t)b * NH * DV + h * DV + j) * HW + pix0 + pl] = d[r] + fmaf(ah, p.bc[h * DV + j], apl[h][j][pl]);
+            }
         }
-        __syncthreads();
     }
     LT_STAMP(5);
 }
@@ -966,6 +995,8 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
 //                       gx = rstd (gamma d xhat - m1 - xn m2)
 constexpr int SPT = 32;      // pixels per streaming backward tile
 constexpr int SCH = 4;       // time steps per staged attn / gs chunk
+
+typedef float f32x2s __attribute__((ext_vector_type(2)));
 
 struct StreamBwd {
     float* M;        // [P][16][2]  m1, m2
@@ -1013,6 +1044,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
     float* asl = stl + NH * 2 * SPT;               // [16 h][32]     sum_t attn
     float* gsl = asl + NH * SPT;                   // [16 h][32]     sum_t gs
     float* chk = gsl + NH * SPT;                   // [2][SCH][4][32][4]  staged attn / gs chunk   16 KB
+    float* pel = chk + 2 * SCH * 4 * SPT * 4;      // [T][16]  positional table of this batch element
     const int T = p.T, HW = p.HW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = lane & 31, hf = lane >> 5;
@@ -1026,6 +1058,8 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
 
     LT_STAMP_B(0);
     // ---- S1: wave = head
+    for (int e = threadIdx.x; e < T * DV; e += 1024) pel[e] = p.pe[(size_t)b * T * DV + e];
+    __syncthreads();
     {
         const int h = w;
         if (hf == 0) {
@@ -1035,18 +1069,33 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
         float ge[DV];
 #pragma unroll
         for (int j = 0; j < DV; ++j) ge[j] = p.g_emb[((size_t)b * NH * DV + h * DV + j) * HW + pix];
-        // r[h][c] for all channels (weights stay wave-uniform = scalar operands; both halves compute, each half stores
-        // the channels it will read in phase A)
-#pragma unroll 2
-        for (int c4 = 0; c4 < C / 4; ++c4) {
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        // r[h][c][px] = sum_j Wc[16h+j][c] ge[16h+j][px] on the MFMA (v_mfma_f32_16x16x4_f32): per head a
+        // [64 c x 16 j] x [16 j x 32 px] product = 4 channel tiles x 2 pixel tiles x 4 k-steps.  D[c = 16mt + 4(l>>4) + r]
+        // [px = 16nt + (l&15)] is exactly one float4 of the LDS layout [h][c/4][px][4].  (The VALU version with scalar
+        // weight operands spent 57k cycles here, mostly waiting for 256 s_load_dwordx4 per wave.)
+        {
+            const int mi = lane & 15, mk = lane >> 4;
+            float gb_[4][2];
 #pragma unroll
-            for (int j = 0; j < DV; ++j) {
-                const float* wr = p.Wc + (size_t)(h * DV + j) * C + c4 * 4;
-                r[0] = fmaf(ge[j], wr[0], r[0]); r[1] = fmaf(ge[j], wr[1], r[1]);
-                r[2] = fmaf(ge[j], wr[2], r[2]); r[3] = fmaf(ge[j], wr[3], r[3]);
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int pl = pix0 + nt * 16 + mi;
+                    gb_[ks][nt] = p.g_emb[((size_t)b * NH * DV + h * DV + 4 * ks + mk) * HW + (pl < HW ? pl : HW - 1)];
+                }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float wa_[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wa_[ks] = p.Wc[(size_t)(h * DV + 4 * ks + mk) * C + mt * 16 + mi];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_[ks], gb_[ks][nt], d, 0, 0, 0);
+                    *reinterpret_cast<f32x4*>(rl + ((size_t)(h * (C / 4) + mt * 4 + mk) * SPT + nt * 16 + mi) * 4) = d;
+                }
             }
-            if ((c4 >> 3) == hf) *reinterpret_cast<f32x4*>(rl + ((size_t)(h * (C / 4) + c4) * SPT + px) * 4) = r;
         }
         float gebc = 0.f;
 #pragma unroll
@@ -1067,7 +1116,11 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
                 if (t < T) {
                     float c0 = gebc + gv[u];
 #pragma unroll
-                    for (int j = 0; j < DV; ++j) c0 = fmaf(ge[j], p.pe[(b * T + t) * DV + j], c0);
+                    for (int jq = 0; jq < DV / 4; ++jq) {           // wave-uniform address: LDS broadcast reads
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(pel + t * DV + 4 * jq);
+                        c0 = fmaf(ge[4 * jq + 0], pv[0], c0); c0 = fmaf(ge[4 * jq + 1], pv[1], c0);
+                        c0 = fmaf(ge[4 * jq + 2], pv[2], c0); c0 = fmaf(ge[4 * jq + 3], pv[3], c0);
+                    }
                     asum += av[u];
                     if (act) p.GS[((size_t)(h * p.B + b) * T + t) * HW + pix] = c0;
                 }
@@ -1204,6 +1257,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
                 }
             }
         }
+        LT_STAMP_B(6);
         // normalised sums: sum_t w xn = rstd * W_raw - mean rstd * sum_t w
         const float rs = stl[(g * 2 + 0) * SPT + px], nm = stl[(g * 2 + 1) * SPT + px];
         float gmk[2], btk[2];
@@ -1213,25 +1267,37 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
             btk[k] = hf ? p.beta[g * CPG + 2 + k] : p.beta[g * CPG + k];
         }
         float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+        // Z part first (consumes Z_raw and r), then the V part (consumes V_raw, writes V over r in LDS): two short loops keep
+        // fewer values live than one, and the LDS stores of the second do not interleave with the r loads of the first
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const float as = asl[h * SPT + px], gss = gsl[h * SPT + px];
-            float* rp = rl + ((size_t)(h * (C / 4) + g) * SPT + px) * 4 + 2 * hf;
+            const float as = asl[h * SPT + px];
+            const f32x2s r2 = *reinterpret_cast<const f32x2s*>(rl + ((size_t)(h * (C / 4) + g) * SPT + px) * 4 + 2 * hf);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int c = c0 + k;
                 const float zt = fmaf(rs, Zr[h][k], nm * as);
+                dg[k] = fmaf(r2[k], zt, dg[k]);
+                db[k] = fmaf(r2[k], as, db[k]);
+                if (act) p.Z[(((size_t)b * NH + h) * C + c0 + k) * HW + pix] = fmaf(gmk[k], zt, btk[k] * as);   // for d Wc
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float gss = gsl[h * SPT + px];
+            f32x2s v2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
                 const float vt = fmaf(rs, Vr[h][k], nm * gss);
                 const float u = hf ? p.U[h * C + g * CPG + 2 + k] : p.U[h * C + g * CPG + k];
-                const float r = rp[k];
-                dg[k] += r * zt + u * vt;
-                db[k] += r * as + u * gss;
-                // Z (xhat-based) for d Wc; V (xhat-based) for d U replaces r in LDS (only this lane reads that slot)
-                if (act) p.Z[(((size_t)b * NH + h) * C + c) * HW + pix] = fmaf(gmk[k], zt, btk[k] * as);
-                rp[k] = act ? fmaf(gmk[k], vt, btk[k] * gss) : 0.f;
+                dg[k] = fmaf(u, vt, dg[k]);
+                db[k] = fmaf(u, gss, db[k]);
+                v2[k] = act ? fmaf(gmk[k], vt, btk[k] * gss) : 0.f;           // V (xhat-based) for d U
             }
-            __builtin_amdgcn_sched_barrier(0);       // one head at a time: keeps the store addresses from all being live
+            *reinterpret_cast<f32x2s*>(rl + ((size_t)(h * (C / 4) + g) * SPT + px) * 4 + 2 * hf) = v2;   // only this lane reads the slot
+            __builtin_amdgcn_sched_barrier(0);
         }
+        LT_STAMP_B(7);
         // d gamma / d beta partials of the tile; GroupNorm-backward means of the group
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -1271,8 +1337,9 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams 
 template <int CPG>
 __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, StreamBwd sb) {
     constexpr int C = CPG * NH;
-    __shared__ float chk[2 * SCH * 4 * SPT * 4];              // staged attn / gs chunk
-    __shared__ float gel[NH * DV * SPT];                      // g_emb of the tile, [h][j/4][32 px][4]
+    extern __shared__ float lds[];
+    float* rl = lds;                                          // [16 h][C/4][32 px][4]  r, as in the heads kernel (128 KB)
+    float* chk = rl + NH * C * SPT;                           // staged attn / gs chunk
     const int T = p.T, HW = p.HW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = lane & 31, hf = lane >> 5;
@@ -1283,31 +1350,40 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, 
     const int pix = act ? pix0 + px : HW - 1;
     const long pidx = (long)b * HW + pix;
     const int g = w, c0 = g * CPG + 2 * hf;
-    // g_emb rows of head w -> LDS (every wave needs all 256 of them)
+    // r[h][c][px] = sum_j Wc[16h+j][c] ge[16h+j][px] on the MFMA, wave = head (same block as in the heads kernel; the
+    // VALU form with scalar weight operands waits on ~1000 scalar loads per wave)
+    {
+        const int h = w, mi = lane & 15, mk = lane >> 4;
+        float gb_[4][2];
 #pragma unroll
-    for (int i = 0; i < DV / 2; ++i) {
-        const int j = hf * (DV / 2) + i;
-        gel[((w * (DV / 4) + (j >> 2)) * SPT + px) * 4 + (j & 3)] = p.g_emb[((size_t)b * NH * DV + w * DV + j) * HW + pix];
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int pl = pix0 + nt * 16 + mi;
+                gb_[ks][nt] = p.g_emb[((size_t)b * NH * DV + h * DV + 4 * ks + mk) * HW + (pl < HW ? pl : HW - 1)];
+            }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float wa_[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wa_[ks] = p.Wc[(size_t)(h * DV + 4 * ks + mk) * C + mt * 16 + mi];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_[ks], gb_[ks][nt], d, 0, 0, 0);
+                *reinterpret_cast<f32x4*>(rl + ((size_t)(h * (C / 4) + mt * 4 + mk) * SPT + nt * 16 + mi) * 4) = d;
+            }
+        }
     }
     __syncthreads();
-    // r and U of the two channels of this lane.  The four channels of the group are computed with wave-uniform
-    // (scalar) weights and the half selects its pair.
+    // r and U of the two channels of this lane (wave = group from here on)
     float r[NH][2], u[NH][2];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        float ra[CPG] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jq = 0; jq < DV / 4; ++jq) {
-            const f32x4 ge = *reinterpret_cast<const f32x4*>(gel + ((h * (DV / 4) + jq) * SPT + px) * 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float* wr = p.Wc + (size_t)(h * DV + jq * 4 + k) * C + g * CPG;
-#pragma unroll
-                for (int cc = 0; cc < CPG; ++cc) ra[cc] = fmaf(ge[k], wr[cc], ra[cc]);
-            }
-        }
-        r[h][0] = hf ? ra[2] : ra[0];
-        r[h][1] = hf ? ra[3] : ra[1];
+        const f32x2s r2 = *reinterpret_cast<const f32x2s*>(rl + ((size_t)(h * (C / 4) + g) * SPT + px) * 4 + 2 * hf);
+        r[h][0] = r2[0];
+        r[h][1] = r2[1];
         u[h][0] = hf ? p.U[h * C + g * CPG + 2] : p.U[h * C + g * CPG + 0];
         u[h][1] = hf ? p.U[h * C + g * CPG + 3] : p.U[h * C + g * CPG + 1];
     }
@@ -1500,6 +1576,7 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_stream_bwd_heads_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_stream_bwd_gx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     StreamBwd sb = {};
@@ -1507,10 +1584,11 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         // the V area of the workspace is not used by the streaming kernels: it holds M [P][16][2] and part_U [tiles][16][C]
         sb.M = p.V;
         sb.part_U = p.V + (size_t)d->B * d->HW * NH * 2;
-        const size_t lds1 = ((size_t)NH * d->C * SPT + NH * 2 * SPT + 2 * NH * SPT + 2 * SCH * 4 * SPT * 4) * sizeof(float);
+        const size_t lds1 = ((size_t)NH * d->C * SPT + NH * 2 * SPT + 2 * NH * SPT + 2 * SCH * 4 * SPT * 4 + (size_t)d->T * DV) * sizeof(float);
         hipLaunchKernelGGL(ltae_stream_bwd_heads_kernel<4>, dim3(tiles), dim3(1024), lds1, st, p, sb);
         C2S_CHECK_LAUNCH("ltae_stream_bwd_heads");
-        hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), 0, st, p, sb);
+        const size_t lds2 = ((size_t)NH * d->C * SPT + 2 * SCH * 4 * SPT * 4) * sizeof(float);
+        hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), lds2, st, p, sb);
         C2S_CHECK_LAUNCH("ltae_stream_bwd_gx");
     } else {
         hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);

@@ -48,6 +48,7 @@ for k, n in enumerate(names):
     print(f"{n:14s} median {np.median(v):9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles")
 v = s[:, 5] - s[:, 0]
 print(f"{'total':14s} median {np.median(v):9.0f}")
+print(f"P5 round 0: write z + barriers {np.median(s[:, 6] - s[:, 4]):9.0f} | Wc loads + 16 MFMA {np.median(s[:, 7] - s[:, 6]):9.0f} cycles")
 
 buf = np.zeros(4096 * 8, dtype=np.uint64)
 lib.c2s_debug_ltae_stamps_bwd.argtypes = [C.c_void_p]
@@ -59,3 +60,4 @@ for k, n in enumerate(["S1 r, c0", "A dots", "B softmax bwd", "C V/Z + means", "
     v = s[:, k + 1] - s[:, k]
     print(f"{n:14s} median {np.median(v):9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles")
 print(f"{'total':14s} median {np.median(s[:, 5] - s[:, 0]):9.0f}")
+print(f"C split: t loop {np.median(s[:, 6] - s[:, 3]):9.0f} | per-head epilogue {np.median(s[:, 7] - s[:, 6]):9.0f} | means + partials {np.median(s[:, 4] - s[:, 7]):9.0f}")
