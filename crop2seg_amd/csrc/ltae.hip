@@ -598,6 +598,138 @@ __global__ __launch_bounds__(256) void gwc_mfma_kernel(const float* __restrict__
         part[((size_t)slice * NH * DV + h * DV + 4 * (lane >> 4) + r) * C + w * 16 + (lane & 15)] = acc[r];
 }
 
+// ------------------------------------------------------------------------------------------ parameter fold
+// Parameter-only part of the re-association, d_model = 256, n_head = 16, d_k = 4:
+//   qWk[h][m] = (1/2) sum_d Q[h][d] Wk[4h+d][m]                    (1/sqrt(d_k) = 1/2)
+//   U[h][c]   = sum_m qWk[h][m] Wc[m][c]
+//   s0[b,t,h] = sum_j (sum_{m = j mod 16} qWk[h][m]) pe[b,t,j] + sum_m qWk[h][m] bc[m] + (1/2) sum_d Q[h][d] bk[4h+d]
+// One workgroup each for the forward and its adjoint (a few MFLOP); fixed summation orders.
+// Replaces positional_encoding.py:16-33 and the key/query algebra of tae.py:790-830 on the parameter side.
+constexpr int DM = NH * DV;      // 256
+constexpr int DK = 4;
+
+__global__ void positional_table_kernel(const long long* __restrict__ dates, float* __restrict__ pe, long n, float period) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= n * DV) return;
+    const int j = (int)(e % DV);
+    const float denom = powf(period, (float)(2 * (j / 2)) / (float)DV);
+    const float a = (float)dates[e / DV] / denom;
+    pe[e] = (j & 1) ? cosf(a) : sinf(a);
+}
+
+__global__ __launch_bounds__(1024) void ltae_fold_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
+                                                             const float* __restrict__ bk, const float* __restrict__ Wc,
+                                                             const float* __restrict__ bc, const float* __restrict__ pe,
+                                                             float* __restrict__ U, float* __restrict__ s0,
+                                                             float* __restrict__ qwk, int BT, int C) {
+    __shared__ float q[NH * DM];
+    __shared__ float qs[NH * DV];
+    __shared__ float k0[NH];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NH * DM; e += 1024) {
+        const int h = e / DM, m = e % DM;
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) v = fmaf(Q[h * DK + d], Wk[(size_t)(h * DK + d) * DM + m], v);
+        v *= 0.5f;
+        q[e] = v;
+        qwk[e] = v;
+    }
+    __syncthreads();
+    if (tid < NH * DV) {
+        const int h = tid / DV, j = tid % DV;
+        float v = 0.f;
+        for (int i = 0; i < DM / DV; ++i) v += q[h * DM + i * DV + j];
+        qs[tid] = v;
+    }
+    if (tid >= 512 && tid < 512 + NH) {
+        const int h = tid - 512;
+        float v = 0.f;
+        for (int m = 0; m < DM; ++m) v = fmaf(q[h * DM + m], bc[m], v);
+        float qb = 0.f;
+        for (int d = 0; d < DK; ++d) qb = fmaf(Q[h * DK + d], bk[h * DK + d], qb);
+        k0[h] = v + 0.5f * qb;
+    }
+    __syncthreads();
+    for (int e = tid; e < NH * C; e += 1024) {
+        const int h = e / C, c = e % C;
+        float v = 0.f;
+        for (int m = 0; m < DM; ++m) v = fmaf(q[h * DM + m], Wc[(size_t)m * C + c], v);
+        U[e] = v;
+    }
+    for (int e = tid; e < BT * NH; e += 1024) {
+        const int bt = e / NH, h = e % NH;
+        float v = k0[h];
+#pragma unroll
+        for (int j = 0; j < DV; ++j) v = fmaf(qs[h * DV + j], pe[(size_t)bt * DV + j], v);
+        s0[e] = v;
+    }
+}
+
+// adjoint: given gU [16][C], gs0 [BT][16] and the attention kernel's direct d Wc / d bc (or NULL), writes the final
+// gradients of Q, fc1_k.weight, fc1_k.bias, inconv.weight, inconv.bias (accumulating where acc_* is set)
+__global__ __launch_bounds__(1024) void ltae_fold_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
+                                                             const float* __restrict__ bk, const float* __restrict__ Wc,
+                                                             const float* __restrict__ bc, const float* __restrict__ pe,
+                                                             const float* __restrict__ qwk, const float* __restrict__ gU,
+                                                             const float* __restrict__ gs0, const float* __restrict__ gWc_attn,
+                                                             const float* __restrict__ gbc_attn, float* __restrict__ gQ,
+                                                             float* __restrict__ gWk, float* __restrict__ gbk,
+                                                             float* __restrict__ gWc, float* __restrict__ gbc, int BT, int C,
+                                                             int acc_q, int acc_wk, int acc_bk, int acc_wc, int acc_bc) {
+    __shared__ float gq[NH * DM];
+    __shared__ float S[NH];          // sum_bt gs0[bt][h]
+    __shared__ float P[NH * DV];     // sum_bt gs0[bt][h] pe[bt][j]
+    const int tid = threadIdx.x;
+    if (tid < NH * DV) {
+        const int h = tid / DV, j = tid % DV;
+        float v = 0.f;
+        for (int bt = 0; bt < BT; ++bt) v = fmaf(gs0[(size_t)bt * NH + h], pe[(size_t)bt * DV + j], v);
+        P[tid] = v;
+    }
+    if (tid >= 512 && tid < 512 + NH) {
+        const int h = tid - 512;
+        float v = 0.f;
+        for (int bt = 0; bt < BT; ++bt) v += gs0[(size_t)bt * NH + h];
+        S[h] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NH * DM; e += 1024) {
+        const int h = e / DM, m = e % DM;
+        float v = fmaf(S[h], bc[m], P[h * DV + m % DV]);
+        for (int c = 0; c < C; ++c) v = fmaf(gU[h * C + c], Wc[(size_t)m * C + c], v);
+        gq[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < DM * C; e += 1024) {          // d inconv.weight
+        const int m = e / C, c = e % C;
+        float v = gWc_attn != nullptr ? gWc_attn[e] : 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) v = fmaf(qwk[h * DM + m], gU[h * C + c], v);
+        gWc[e] = acc_wc ? gWc[e] + v : v;
+    }
+    for (int m = tid; m < DM; m += 1024) {              // d inconv.bias
+        float v = gbc_attn != nullptr ? gbc_attn[m] : 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) v = fmaf(qwk[h * DM + m], S[h], v);
+        gbc[m] = acc_bc ? gbc[m] + v : v;
+    }
+    for (int e = tid; e < NH * DK * DM; e += 1024) {    // d fc1_k.weight [64][256]
+        const int hd = e / DM, m = e % DM, h = hd / DK;
+        const float v = 0.5f * Q[hd] * gq[h * DM + m];
+        gWk[e] = acc_wk ? gWk[e] + v : v;
+    }
+    if (tid < NH * DK) {                                // d fc1_k.bias, d Q
+        const int h = tid / DK;
+        const float vb = 0.5f * Q[tid] * S[h];
+        gbk[tid] = acc_bk ? gbk[tid] + vb : vb;
+        float v = bk[tid] * S[h];
+        for (int m = 0; m < DM; ++m) v = fmaf(gq[h * DM + m], Wk[(size_t)tid * DM + m], v);
+        v *= 0.5f;
+        gQ[tid] = acc_q ? gQ[tid] + v : v;
+    }
+}
+
 // per-pixel GroupNorm over channel groups of a [B,C,HW] tensor (tae.py:437-440,488)
 __global__ void pixel_gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats,
@@ -1638,6 +1770,34 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     } else {
         hipMemsetAsync(gWc, 0, (size_t)256 * d->C * sizeof(float), st);
     }
+    return C2S_OK;
+}
+
+extern "C" int c2s_positional_table(const long long* dates, float* pe, long n, float period, void* stream) {
+    C2S_REQUIRE(dates && pe && n > 0 && period > 0.f, "positional_table: bad args");
+    hipLaunchKernelGGL(positional_table_kernel, dim3(cdiv(n * DV, 256)), dim3(256), 0, (hipStream_t)stream, dates, pe, n, period);
+    C2S_CHECK_LAUNCH("positional_table");
+    return C2S_OK;
+}
+
+extern "C" int c2s_ltae_fold_fwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc,
+                                 const float* pe, float* U, float* s0, float* qwk, int BT, int C, void* stream) {
+    C2S_REQUIRE(Q && Wk && bk && Wc && bc && pe && U && s0 && qwk && BT > 0 && C > 0, "ltae_fold_fwd: bad args");
+    hipLaunchKernelGGL(ltae_fold_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, Q, Wk, bk, Wc, bc, pe, U, s0, qwk, BT, C);
+    C2S_CHECK_LAUNCH("ltae_fold_fwd");
+    return C2S_OK;
+}
+
+extern "C" int c2s_ltae_fold_bwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc,
+                                 const float* pe, const float* qwk, const float* gU, const float* gs0,
+                                 const float* gWc_attn, const float* gbc_attn, float* gQ, float* gWk, float* gbk,
+                                 float* gWc, float* gbc, int BT, int C, int acc_mask, void* stream) {
+    C2S_REQUIRE(Q && Wk && bk && Wc && bc && pe && qwk && gU && gs0 && gQ && gWk && gbk && gWc && gbc && BT > 0 && C > 0,
+                "ltae_fold_bwd: bad args");
+    hipLaunchKernelGGL(ltae_fold_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, Q, Wk, bk, Wc, bc, pe, qwk, gU, gs0,
+                       gWc_attn, gbc_attn, gQ, gWk, gbk, gWc, gbc, BT, C, acc_mask & 1, (acc_mask >> 1) & 1,
+                       (acc_mask >> 2) & 1, (acc_mask >> 3) & 1, (acc_mask >> 4) & 1);
+    C2S_CHECK_LAUNCH("ltae_fold_bwd");
     return C2S_OK;
 }
 

@@ -515,30 +515,12 @@ def temporal_aggregate(ctx: Ctx, x5: Tensor, attn: Tensor, valid: Optional[Tenso
 # L-TAE
 # =================================================================================================
 def positional_table(dates: Tensor, d: int, period: float) -> Tensor:
-    """[B,T] int days -> [B,T,d] sinusoid table (reference positional_encoding.py:16-33); host-side table."""
-    i = torch.arange(d, device=dates.device, dtype=torch.float32)
-    # scalar ** tensor: no host->device copy (the call must stay hipGraph-capturable)
-    denom = torch.pow(float(period), 2 * torch.div(i, 2, rounding_mode="floor") / d)
-    tab = dates.to(torch.float32)[:, :, None] / denom[None, None, :]
-    out = torch.empty_like(tab)
-    out[..., 0::2] = torch.sin(tab[..., 0::2])
-    out[..., 1::2] = torch.cos(tab[..., 1::2])
-    return out
-
-
-def _fold_attention_params(Q: Tensor, Wk: Tensor, bk: Tensor, Wc: Tensor, bc: Tensor, pe: Tensor, n_head: int,
-                           d_k: int) -> Tuple[Tensor, Tensor]:
-    """Parameter-only folding: U [H,C] and s0 [B,T,H] such that
-    score[h,t] = U[h] . xhat_t + s0[b,t,h] equals q_h . (Wk_h (Wc xhat_t + bc + pe_t) + bk_h) / sqrt(d_k)."""
-    H = n_head
-    dm = Wk.shape[1]
-    scale = 1.0 / (d_k ** 0.5)
-    qWk = torch.einsum("hd,hdm->hm", Q[:, 0, :], Wk.view(H, d_k, dm)) * scale          # [H,dm]
-    U = qWk @ Wc                                                                      # [H,C]
-    pe_full = pe.repeat(1, 1, H)                                                      # [B,T,dm]
-    s0 = torch.einsum("hm,btm->bth", qWk, pe_full + bc[None, None, :])
-    s0 = s0 + (torch.einsum("hd,hd->h", Q[:, 0, :], bk.view(H, d_k)) * scale)[None, None, :]
-    return U.contiguous(), s0.contiguous()
+    """[B,T] int days -> [B,T,16] sinusoid table (reference positional_encoding.py:16-33)."""
+    assert d == 16, "the kernels are built for d_model / n_head = 16"
+    dl = dates.to(torch.int64).contiguous()
+    pe = torch.empty(*dl.shape, d, device=dl.device, dtype=torch.float32)
+    check(lib().c2s_positional_table(dl.data_ptr(), pe.data_ptr(), dl.numel(), float(period), _stream()), "positional_table")
+    return pe
 
 
 def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor], prefix: str, n_head: int, d_k: int,
@@ -553,15 +535,15 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     Wc3 = ctx.p[prefix + ".inconv.weight"]
     bc = ctx.p[prefix + ".inconv.bias"]
     gamma, beta = ctx.p[prefix + ".in_norm.weight"], ctx.p[prefix + ".in_norm.bias"]
-    pe = positional_table(dates, d_model // n_head, period).contiguous()
-    leaves = None
-    if ctx.tape is not None:
-        leaves = [t.detach().clone().requires_grad_(True) for t in (Q, Wk, bk, Wc3, bc)]
-        with torch.enable_grad():
-            U, s0 = _fold_attention_params(leaves[0], leaves[1], leaves[2], leaves[3][:, :, 0], leaves[4], pe, n_head, d_k)
-    else:
-        with torch.no_grad():
-            U, s0 = _fold_attention_params(Q, Wk, bk, Wc3[:, :, 0], bc, pe, n_head, d_k)
+    assert n_head == 16 and d_k == 4 and d_model == 256, "the fold kernels are built for n_head=16, d_k=4, d_model=256"
+    pe = positional_table(dates, d_model // n_head, period)
+    # parameter-only fold: U [16,C], s0 [B,T,16]; qwk is kept for the adjoint
+    dev = x5.device
+    U = torch.empty(n_head, Cc, device=dev, dtype=torch.float32)
+    s0 = torch.empty(B, T, n_head, device=dev, dtype=torch.float32)
+    qwk = torch.empty(n_head, d_model, device=dev, dtype=torch.float32)
+    check(lib().c2s_ltae_fold_fwd(Q.data_ptr(), Wk.data_ptr(), bk.data_ptr(), Wc3.data_ptr(), bc.data_ptr(), pe.data_ptr(),
+                                  U.data_ptr(), s0.data_ptr(), qwk.data_ptr(), B * T, Cc, _stream()), "ltae_fold_fwd")
     Wc = Wc3.view(d_model, Cc)
     p_eff = dropout_p if ctx.training else 0.0
     d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None, _ptr(seed_dev))
@@ -569,7 +551,7 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     attn_pre = torch.empty_like(attn)          # softmax before dropout (backward); score scratch of the streaming kernels
     emb = torch.empty(B, d_model, h, w, device=x5.device, dtype=torch.float32) if with_embedding else None
     stats = torch.empty(B * HW * n_head * 2, device=x5.device, dtype=torch.float32)
-    Ud, s0d = U.detach(), s0.detach()
+    Ud, s0d = U, s0
     fws = ctx.ws.get("ltae_fwd", lib().c2s_ltae_fwd_workspace_floats(C.byref(d)))
     check(lib().c2s_ltae_attn_fwd_ws(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
                                      s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
@@ -602,15 +584,15 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
                                       attn.data_ptr(), attn_pre.data_ptr(), stats.data_ptr(), _ptr(g_emb), _ptr(g_attn),
                                       gx.data_ptr(), gU.data_ptr(), gs0.data_ptr(), gWc.data_ptr(), gbc.data_ptr(),
                                       ggam.data_ptr(), gbet.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ltae_bwd")
-        # chain the folded parameters back to Q, fc1_k, inconv (tiny parameter-only tensors)
-        gl = torch.autograd.grad([U, s0], leaves, [gU, gs0], allow_unused=True)
+        # adjoint of the parameter fold: final gradients of Q, fc1_k, inconv in one launch
         names = [prefix + ".attention_head.Q", prefix + ".attention_head.fc1_k.weight",
                  prefix + ".attention_head.fc1_k.bias", prefix + ".inconv.weight", prefix + ".inconv.bias"]
-        for nme, gg, leaf in zip(names, gl, leaves):
-            ctx.add_param_grad(nme, gg if gg is not None else torch.zeros_like(leaf))
-        if emb is not None:
-            ctx.add_param_grad(prefix + ".inconv.weight", gWc.view(d_model, Cc, 1))
-            ctx.add_param_grad(prefix + ".inconv.bias", gbc)
+        sinks = [ctx.grad_sink(nme) for nme in names]
+        acc_mask = sum((1 << i) for i, (_, acc) in enumerate(sinks) if acc)
+        check(lib().c2s_ltae_fold_bwd(Q.data_ptr(), Wk.data_ptr(), bk.data_ptr(), Wc3.data_ptr(), bc.data_ptr(), pe.data_ptr(),
+                                      qwk.data_ptr(), gU.data_ptr(), gs0.data_ptr(),
+                                      gWc.data_ptr() if emb is not None else None, gbc.data_ptr() if emb is not None else None,
+                                      *[t.data_ptr() for t, _ in sinks], B * T, Cc, acc_mask, _stream()), "ltae_fold_bwd")
         tape.add_grad(x5, gx)
 
     tape.record(bwd)

@@ -240,6 +240,19 @@ int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const float* gamma
                       const float* g_emb, const float* g_attn, float* gx, float* gU, float* gs0, float* gWc,
                       float* gbc, float* ggamma, float* gbeta, float* workspace, size_t ws_floats, void* stream);
 
+/* Parameter side of the L-TAE re-association, n_head = 16, d_model = 256, d_k = 4:
+ *   c2s_positional_table : pe[b,t,j] = sin / cos(dates[b,t] / period^(2 floor(j/2)/16))   (positional_encoding.py:16-33)
+ *   c2s_ltae_fold_fwd    : U [16,C], s0 [BT,16] from Q [16,1,4], fc1_k (Wk [64,256], bk [64]), inconv (Wc [256,C], bc [256])
+ *                          and pe [BT,16]; qwk [16,256] is saved for the adjoint
+ *   c2s_ltae_fold_bwd    : final gradients of Q, Wk, bk, Wc, bc from gU, gs0 (+ the attention kernel's direct d Wc / d bc,
+ *                          may be NULL); acc_mask bit i set = accumulate into output i (order gQ, gWk, gbk, gWc, gbc) */
+int c2s_positional_table(const long long* dates, float* pe, long n, float period, void* stream);
+int c2s_ltae_fold_fwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc, const float* pe,
+                      float* U, float* s0, float* qwk, int BT, int C, void* stream);
+int c2s_ltae_fold_bwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc, const float* pe,
+                      const float* qwk, const float* gU, const float* gs0, const float* gWc_attn, const float* gbc_attn,
+                      float* gQ, float* gWk, float* gbk, float* gWc, float* gbc, int BT, int C, int acc_mask, void* stream);
+
 /* L-TAE tail (tae.py:442-449,486-488).  Linear(256,C') is a 1x1 convolution on the NCHW embedding
  * (c2s_conv_igemm), BatchNorm1d over P is c2s_norm_* with kind BATCH; the two pieces below are the rest:
  * Dropout(0.2) with the keep mask indexed pixel-major [P,C] like the reference's activations, and the
