@@ -57,6 +57,10 @@ SIGNATURES = {
     "c2s_last_error": (C.c_char_p, []),
     "c2s_device_cus": (I, []),
     "c2s_pack_weights": (I, [P, P, I, I, I, I, L, L, C.POINTER(I), P]),
+    "c2s_pack_job_bytes": (SZ, []),
+    "c2s_pack_job_fill": (I, [P, P, P, I, I, I, I, L, L, I, C.POINTER(I), I]),
+    "c2s_pack_job_blocks": (I, [I, I, I, I]),
+    "c2s_pack_batch": (I, [P, I, I, P]),
     "c2s_conv_igemm": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "c2s_conv_xpair": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P]),
     "c2s_winograd_packed_floats": (SZ, [I, I]),

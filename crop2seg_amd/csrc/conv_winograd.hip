@@ -402,6 +402,58 @@ __global__ void pack_winograd_kernel(const float* __restrict__ src, float* __res
     }
 }
 
+// ---- all per-step weight packs in one launch: a device table of jobs (plain tap-major packs for the direct / transposed
+// kernels and Winograd transforms); block -> job by the table's block offsets
+struct PackJob {
+    const float* src;
+    float* dst;
+    long so, sc;
+    int cin, cout, coutP, ntaps;
+    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U
+    int block_start;     // first block of this job
+    int taps[16];
+};
+
+__global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;      // <= ~64 jobs: linear scan
+    const PackJob& jb = jobs[j];
+    const long e = (long)(blockIdx.x - jb.block_start) * blockDim.x + threadIdx.x;
+    if (jb.kind == 0) {
+        const long total = (long)jb.ntaps * jb.cin * jb.coutP;
+        if (e >= total) return;
+        const int o = (int)(e % jb.coutP);
+        const long tc = e / jb.coutP;
+        const int c = (int)(tc % jb.cin), t = (int)(tc / jb.cin);
+        jb.dst[e] = o < jb.cout ? jb.src[o * jb.so + c * jb.sc + jb.taps[t]] : 0.f;
+        return;
+    }
+    const int nchunks = (jb.cin + WN_CK - 1) / WN_CK;
+    const long total = (long)nchunks * WN_CK * jb.coutP;
+    if (e >= total) return;
+    const int o = (int)(e % jb.coutP), c = (int)(e / jb.coutP);
+    const bool real = o < jb.cout && c < jb.cin;
+    float g[3][3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = real ? jb.src[o * jb.so + c * jb.sc + jb.taps[k]] : 0.f;
+    float t[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        t[0][q] = g[0][q];
+        t[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+        t[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+        t[3][q] = g[2][q];
+    }
+    float* base = jb.dst + ((size_t)(o >> 6) * nchunks + (c >> 3)) * WN_USLAB + (c & 7) * 64 + (o & 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        base[(i * 4 + 0) * WN_CK * 64] = t[i][0];
+        base[(i * 4 + 1) * WN_CK * 64] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+        base[(i * 4 + 2) * WN_CK * 64] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+        base[(i * 4 + 3) * WN_CK * 64] = t[i][2];
+    }
+}
+
 }  // namespace
 
 extern "C" size_t c2s_winograd_packed_floats(int cin, int coutP) {
@@ -413,6 +465,33 @@ extern "C" int c2s_debug_winograd_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wn_stamps), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : 1;
 }
 #endif
+
+extern "C" size_t c2s_pack_job_bytes(void) { return sizeof(PackJob); }
+
+// Fill one job record of a host-side table (the caller uploads the table once and reuses it every step)
+extern "C" int c2s_pack_job_fill(void* host_record, const float* src, float* dst, int cin, int cout, int coutP, int ntaps,
+                                 long stride_o, long stride_c, int winograd, const int* host_tap_off, int block_start) {
+    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16, "pack_job_fill: bad args");
+    PackJob* j = reinterpret_cast<PackJob*>(host_record);
+    j->src = src; j->dst = dst; j->so = stride_o; j->sc = stride_c;
+    j->cin = cin; j->cout = cout; j->coutP = coutP; j->ntaps = ntaps; j->kind = winograd ? 1 : 0; j->block_start = block_start;
+    for (int i = 0; i < 16; ++i) j->taps[i] = i < ntaps ? host_tap_off[i] : 0;
+    return C2S_OK;
+}
+
+// blocks (of 256 threads) a job needs
+extern "C" int c2s_pack_job_blocks(int cin, int coutP, int ntaps, int winograd) {
+    const long total = winograd ? (long)cdiv(cin, WN_CK) * WN_CK * coutP : (long)ntaps * cin * coutP;
+    return cdiv(total, 256);
+}
+
+extern "C" int c2s_pack_batch(const void* device_table, int njobs, int total_blocks, void* stream) {
+    C2S_REQUIRE(device_table && njobs > 0 && total_blocks > 0, "pack_batch: bad args");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackJob*>(device_table), njobs);
+    C2S_CHECK_LAUNCH("pack_batch");
+    return C2S_OK;
+}
 
 extern "C" int c2s_pack_weights_winograd(const float* src, float* upk, int cin, int cout, int coutP, long stride_o,
                                          long stride_c, const int* host_tap_off, void* stream) {

@@ -36,6 +36,29 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, Tensor] = {}
+        # weight-pack plan: the jobs recorded during one step become a device table that later steps run in one launch
+        self.pack_record: Dict[Tuple, Tuple] = {}
+        self.pack_plan: Optional[dict] = None
+
+    def finalize_pack_plan(self) -> None:
+        """Turn the packs recorded during the step that just ran into a one-launch plan (host -> device table copy:
+        call outside hipGraph capture; TrainStep does it at the end of every eager forward/backward)."""
+        if self.pack_plan is not None or not self.pack_record:
+            return
+        L_ = lib()
+        rec_bytes = L_.c2s_pack_job_bytes()
+        jobs = list(self.pack_record.items())
+        table = torch.zeros(len(jobs) * rec_bytes, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else \
+            torch.zeros(len(jobs) * rec_bytes, dtype=torch.uint8)
+        outs, block = {}, 0
+        for i, (key, (src_ptr, cin, cout, coutP, ntaps, so, sc, wino, taps, nfloats)) in enumerate(jobs):
+            out = torch.empty(nfloats, device=self.device, dtype=torch.float32)
+            check(L_.c2s_pack_job_fill(table.data_ptr() + i * rec_bytes, src_ptr, out.data_ptr(), cin, cout, coutP, ntaps, so, sc,
+                                       wino, _tap_array(taps), block), "pack_job_fill")
+            block += L_.c2s_pack_job_blocks(cin, coutP, ntaps, wino)
+            outs[key] = (out, src_ptr)
+        self.pack_plan = {"table": table.to(self.device), "njobs": len(jobs), "blocks": block, "outs": outs}
+        self.pack_record = {}
 
     def get(self, name: str, nfloats: int) -> Tensor:
         b = self.bufs.get(name)
@@ -97,6 +120,7 @@ class Ctx:
         self.momentum = momentum
         self.device = ws.device
         self._packed: Dict[Tuple, Tensor] = {}
+        self._plan_ran = False
         self._gwritten: set = set()
         cus = lib().c2s_device_cus()
         self.cus = cus if cus > 0 else 256
@@ -116,6 +140,22 @@ class Ctx:
             dst.copy_(g.view_as(dst))
 
     # -- weight packing --------------------------------------------------------------------------
+    def _planned(self, key: Tuple, src_ptr: int) -> Optional[Tensor]:
+        """Packed weights from the one-launch plan (run at the first pack request of the step), if the plan covers `key`
+        for this source pointer; a stale plan (parameters re-allocated) is dropped."""
+        plan = self.ws.pack_plan
+        if plan is None:
+            return None
+        hit = plan["outs"].get(key)
+        if hit is None or hit[1] != src_ptr:
+            self.ws.pack_plan = None
+            self.ws.pack_record = {}
+            return None
+        if not self._plan_ran:
+            check(lib().c2s_pack_batch(plan["table"].data_ptr(), plan["njobs"], plan["blocks"], _stream()), "pack_batch")
+            self._plan_ran = True
+        return hit[0]
+
     def pack(self, key: Tuple, src: Tensor, src_off: int, cin: int, cout: int, ntaps: int, so: int, sc: int,
              taps: Sequence[int]) -> Tuple[Tensor, int]:
         """Pack (cached per forward) weights into [ntaps][cin][coutP]."""
@@ -123,9 +163,13 @@ class Ctx:
         coutP = (cout + 31) // 32 * 32
         if hit is not None:
             return hit, coutP
-        wpk = torch.empty(ntaps * cin * coutP, device=self.device, dtype=torch.float32)
-        check(lib().c2s_pack_weights(src.data_ptr() + 4 * src_off, wpk.data_ptr(), cin, cout, coutP, ntaps, so, sc,
-                                     _tap_array(taps), _stream()), "pack_weights")
+        src_ptr = src.data_ptr() + 4 * src_off
+        wpk = self._planned(key, src_ptr)
+        if wpk is None:
+            wpk = torch.empty(ntaps * cin * coutP, device=self.device, dtype=torch.float32)
+            check(lib().c2s_pack_weights(src_ptr, wpk.data_ptr(), cin, cout, coutP, ntaps, so, sc, _tap_array(taps), _stream()),
+                  "pack_weights")
+            self.ws.pack_record[key] = (src_ptr, cin, cout, coutP, ntaps, so, sc, 0, tuple(taps), ntaps * cin * coutP)
         self._packed[key] = wpk
         return wpk, coutP
 
@@ -152,9 +196,14 @@ def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, 
     coutP = (cout + 63) // 64 * 64
     if hit is not None:
         return hit, coutP
-    upk = torch.empty(lib().c2s_winograd_packed_floats(cin, coutP), device=ctx.device, dtype=torch.float32)
-    check(lib().c2s_pack_weights_winograd(src.data_ptr() + 4 * src_off, upk.data_ptr(), cin, cout, coutP, so, sc,
-                                          _tap_array(taps), _stream()), "pack_weights_winograd")
+    src_ptr = src.data_ptr() + 4 * src_off
+    upk = ctx._planned(key, src_ptr)
+    if upk is None:
+        nfl = lib().c2s_winograd_packed_floats(cin, coutP)
+        upk = torch.empty(nfl, device=ctx.device, dtype=torch.float32)
+        check(lib().c2s_pack_weights_winograd(src_ptr, upk.data_ptr(), cin, cout, coutP, so, sc, _tap_array(taps), _stream()),
+              "pack_weights_winograd")
+        ctx.ws.pack_record[key] = (src_ptr, cin, cout, coutP, 9, so, sc, 1, tuple(taps), nfl)
     ctx._packed[key] = upk
     return upk, coutP
 
@@ -458,8 +507,10 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
         if g is None:
             return
         if residual is not None:
-            tape.add_grad(residual, g, own=False)
-        gx = g  # in place
+            tape.add_grad(residual, g, own=True)      # the residual branch keeps g itself ...
+            gx = torch.empty_like(g)                  # ... and the norm gradient goes to a fresh buffer (no copy of g)
+        else:
+            gx = g  # in place
         dgamma, _ = ctx.grad_sink(prefix + ".weight")
         dbeta, _ = ctx.grad_sink(prefix + ".bias")
         dbias = ctx.grad_sink(conv_bias)[0] if conv_bias else None

@@ -127,6 +127,8 @@ class TrainStep:
         loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True)
         tape.grads[logits.data_ptr()] = glogits
         tape.backward()
+        if not torch.cuda.is_current_stream_capturing():
+            self.ws.finalize_pack_plan()                 # from the second step on, all weight packs are one launch
         for n in self.names:                             # parameters no kernel wrote to (none in the default models)
             if n not in ctx._gwritten:
                 self.grads[n].zero_()

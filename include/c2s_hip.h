@@ -51,6 +51,16 @@ int c2s_device_cus(void);
  * ------------------------------------------------------------------------------------------------ */
 int c2s_pack_weights(const float* src, float* wpk, int cin, int cout, int coutP, int ntaps,
                      long stride_o, long stride_c, const int* host_tap_off, void* stream);
+/* All weight packs of a step in one launch.  The caller builds a table of job records once (host memory, record size
+ * c2s_pack_job_bytes(), filled by c2s_pack_job_fill: plain tap-major pack as c2s_pack_weights, or the Winograd transform of
+ * c2s_pack_weights_winograd), uploads it, and calls c2s_pack_batch(device_table, njobs, total_blocks) every step;
+ * block_start of job i = sum of c2s_pack_job_blocks over the jobs before it. */
+size_t c2s_pack_job_bytes(void);
+int c2s_pack_job_fill(void* host_record, const float* src, float* dst, int cin, int cout, int coutP, int ntaps,
+                      long stride_o, long stride_c, int winograd, const int* host_tap_off, int block_start);
+int c2s_pack_job_blocks(int cin, int coutP, int ntaps, int winograd);
+int c2s_pack_batch(const void* device_table, int njobs, int total_blocks, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on f32 MFMA (v_mfma_f32_32x32x2_f32), forward and data-gradient.
