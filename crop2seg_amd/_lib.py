@@ -83,7 +83,8 @@ SIGNATURES = {
     "c2s_ltae_attn_fwd": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P]),
     "c2s_positional_table": (I, [P, P, L, C.c_float, P]),
     "c2s_ltae_fold_fwd": (I, [P] * 9 + [I, I, P]),
-    "c2s_ltae_fold_bwd": (I, [P] * 16 + [I, I, I, P]),
+    "c2s_ltae_fold_bwd": (I, [P] * 16 + [I, I, I, P, SZ, P]),
+    "c2s_ltae_fold_bwd_workspace_floats": (SZ, []),
     "c2s_ltae_fwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_fwd_ws": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P, SZ, P]),
     "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),

@@ -667,66 +667,82 @@ __global__ __launch_bounds__(1024) void ltae_fold_fwd_kernel(const float* __rest
 }
 
 // adjoint: given gU [16][C], gs0 [BT][16] and the attention kernel's direct d Wc / d bc (or NULL), writes the final
-// gradients of Q, fc1_k.weight, fc1_k.bias, inconv.weight, inconv.bias (accumulating where acc_* is set)
-__global__ __launch_bounds__(1024) void ltae_fold_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
-                                                             const float* __restrict__ bk, const float* __restrict__ Wc,
-                                                             const float* __restrict__ bc, const float* __restrict__ pe,
-                                                             const float* __restrict__ qwk, const float* __restrict__ gU,
-                                                             const float* __restrict__ gs0, const float* __restrict__ gWc_attn,
-                                                             const float* __restrict__ gbc_attn, float* __restrict__ gQ,
-                                                             float* __restrict__ gWk, float* __restrict__ gbk,
-                                                             float* __restrict__ gWc, float* __restrict__ gbc, int BT, int C,
-                                                             int acc_q, int acc_wk, int acc_bk, int acc_wc, int acc_bc) {
-    __shared__ float gq[NH * DM];
-    __shared__ float S[NH];          // sum_bt gs0[bt][h]
-    __shared__ float P[NH * DV];     // sum_bt gs0[bt][h] pe[bt][j]
-    const int tid = threadIdx.x;
-    if (tid < NH * DV) {
-        const int h = tid / DV, j = tid % DV;
-        float v = 0.f;
-        for (int bt = 0; bt < BT; ++bt) v = fmaf(gs0[(size_t)bt * NH + h], pe[(size_t)bt * DV + j], v);
-        P[tid] = v;
+// gradients of Q, fc1_k.weight, fc1_k.bias, inconv.weight, inconv.bias (accumulating where acc_* is set).
+// Three small launches (a single workgroup doing everything took 0.30 ms: serial, uncoalesced reads of Wc):
+//   1  S[h] = sum_bt gs0, P[h][j] = sum_bt gs0 pe         one wave per output, lanes over bt
+//   2  per m (one wave each): gq[h][m] = gU[h].Wc[m] + P[h][m%16] + S[h] bc[m]  (lanes over c: coalesced),
+//      d inconv.weight[m][:], d inconv.bias[m]
+//   3  per (h,d) (one wave each): d fc1_k.weight row, d fc1_k.bias, d Q (lanes over m)
+__global__ __launch_bounds__(64) void ltae_fold_bwd1_kernel(const float* __restrict__ gs0, const float* __restrict__ pe,
+                                                            float* __restrict__ SP, int BT) {
+    const int o = blockIdx.x, lane = threadIdx.x;      // o < 16: S[h]; else P[h][j]
+    float v = 0.f;
+    if (o < NH) {
+        for (int bt = lane; bt < BT; bt += 64) v += gs0[(size_t)bt * NH + o];
+    } else {
+        const int h = (o - NH) / DV, j = (o - NH) % DV;
+        for (int bt = lane; bt < BT; bt += 64) v = fmaf(gs0[(size_t)bt * NH + h], pe[(size_t)bt * DV + j], v);
     }
-    if (tid >= 512 && tid < 512 + NH) {
-        const int h = tid - 512;
-        float v = 0.f;
-        for (int bt = 0; bt < BT; ++bt) v += gs0[(size_t)bt * NH + h];
-        S[h] = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < NH * DM; e += 1024) {
-        const int h = e / DM, m = e % DM;
-        float v = fmaf(S[h], bc[m], P[h * DV + m % DV]);
-        for (int c = 0; c < C; ++c) v = fmaf(gU[h * C + c], Wc[(size_t)m * C + c], v);
-        gq[e] = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < DM * C; e += 1024) {          // d inconv.weight
-        const int m = e / C, c = e % C;
-        float v = gWc_attn != nullptr ? gWc_attn[e] : 0.f;
+    v = wave_sum(v);
+    if (lane == 0) SP[o] = v;
+}
+
+__global__ __launch_bounds__(64) void ltae_fold_bwd2_kernel(const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                            const float* __restrict__ qwk, const float* __restrict__ gU,
+                                                            const float* __restrict__ SP, const float* __restrict__ gWc_attn,
+                                                            const float* __restrict__ gbc_attn, float* __restrict__ gq,
+                                                            float* __restrict__ gWc, float* __restrict__ gbc, int C,
+                                                            int acc_wc, int acc_bc) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const float* S = SP;
+    const float* P = SP + NH;
+    float q[NH];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) v = fmaf(qwk[h * DM + m], gU[h * C + c], v);
-        gWc[e] = acc_wc ? gWc[e] + v : v;
-    }
-    for (int m = tid; m < DM; m += 1024) {              // d inconv.bias
-        float v = gbc_attn != nullptr ? gbc_attn[m] : 0.f;
+    for (int h = 0; h < NH; ++h) q[h] = qwk[h * DM + m];
+    float dot[NH];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) v = fmaf(qwk[h * DM + m], S[h], v);
-        gbc[m] = acc_bc ? gbc[m] + v : v;
+    for (int h = 0; h < NH; ++h) dot[h] = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float w = Wc[(size_t)m * C + c];
+        float v = gWc_attn != nullptr ? gWc_attn[(size_t)m * C + c] : 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float g = gU[h * C + c];
+            dot[h] = fmaf(g, w, dot[h]);
+            v = fmaf(q[h], g, v);
+        }
+        gWc[(size_t)m * C + c] = acc_wc ? gWc[(size_t)m * C + c] + v : v;
     }
-    for (int e = tid; e < NH * DK * DM; e += 1024) {    // d fc1_k.weight [64][256]
-        const int hd = e / DM, m = e % DM, h = hd / DK;
-        const float v = 0.5f * Q[hd] * gq[h * DM + m];
-        gWk[e] = acc_wk ? gWk[e] + v : v;
+    float vb = gbc_attn != nullptr ? gbc_attn[m] : 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float d = wave_sum(dot[h]);
+        if (lane == 0) gq[h * DM + m] = d + fmaf(S[h], bc[m], P[h * DV + m % DV]);
+        vb = fmaf(q[h], S[h], vb);
     }
-    if (tid < NH * DK) {                                // d fc1_k.bias, d Q
-        const int h = tid / DK;
-        const float vb = 0.5f * Q[tid] * S[h];
-        gbk[tid] = acc_bk ? gbk[tid] + vb : vb;
-        float v = bk[tid] * S[h];
-        for (int m = 0; m < DM; ++m) v = fmaf(gq[h * DM + m], Wk[(size_t)tid * DM + m], v);
-        v *= 0.5f;
-        gQ[tid] = acc_q ? gQ[tid] + v : v;
+    if (lane == 0) gbc[m] = acc_bc ? gbc[m] + vb : vb;
+}
+
+__global__ __launch_bounds__(64) void ltae_fold_bwd3_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
+                                                            const float* __restrict__ bk, const float* __restrict__ gq,
+                                                            const float* __restrict__ SP, float* __restrict__ gQ,
+                                                            float* __restrict__ gWk, float* __restrict__ gbk, int acc_q,
+                                                            int acc_wk, int acc_bk) {
+    const int hd = blockIdx.x, h = hd / DK, lane = threadIdx.x;
+    const float qv = Q[hd], S = SP[h];
+    float acc = 0.f;
+    for (int m = lane; m < DM; m += 64) {
+        const float g = gq[h * DM + m];
+        const float v = 0.5f * qv * g;
+        gWk[(size_t)hd * DM + m] = acc_wk ? gWk[(size_t)hd * DM + m] + v : v;
+        acc = fmaf(g, Wk[(size_t)hd * DM + m], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const float vb = 0.5f * qv * S;
+        gbk[hd] = acc_bk ? gbk[hd] + vb : vb;
+        const float vq = 0.5f * (acc + bk[hd] * S);
+        gQ[hd] = acc_q ? gQ[hd] + vq : vq;
     }
 }
 
@@ -1788,16 +1804,27 @@ extern "C" int c2s_ltae_fold_fwd(const float* Q, const float* Wk, const float* b
     return C2S_OK;
 }
 
+extern "C" size_t c2s_ltae_fold_bwd_workspace_floats(void) { return (size_t)NH + NH * DV + NH * DM; }
+
 extern "C" int c2s_ltae_fold_bwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc,
                                  const float* pe, const float* qwk, const float* gU, const float* gs0,
                                  const float* gWc_attn, const float* gbc_attn, float* gQ, float* gWk, float* gbk,
-                                 float* gWc, float* gbc, int BT, int C, int acc_mask, void* stream) {
-    C2S_REQUIRE(Q && Wk && bk && Wc && bc && pe && qwk && gU && gs0 && gQ && gWk && gbk && gWc && gbc && BT > 0 && C > 0,
-                "ltae_fold_bwd: bad args");
-    hipLaunchKernelGGL(ltae_fold_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, Q, Wk, bk, Wc, bc, pe, qwk, gU, gs0,
-                       gWc_attn, gbc_attn, gQ, gWk, gbk, gWc, gbc, BT, C, acc_mask & 1, (acc_mask >> 1) & 1,
-                       (acc_mask >> 2) & 1, (acc_mask >> 3) & 1, (acc_mask >> 4) & 1);
-    C2S_CHECK_LAUNCH("ltae_fold_bwd");
+                                 float* gWc, float* gbc, int BT, int C, int acc_mask, float* workspace, size_t ws_floats,
+                                 void* stream) {
+    C2S_REQUIRE(Q && Wk && bk && Wc && bc && pe && qwk && gU && gs0 && gQ && gWk && gbk && gWc && gbc && workspace && BT > 0 &&
+                    C > 0, "ltae_fold_bwd: bad args");
+    C2S_REQUIRE(ws_floats >= c2s_ltae_fold_bwd_workspace_floats(), "ltae_fold_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* SP = workspace;                    // S [16] | P [16][16]
+    float* gq = workspace + NH + NH * DV;     // [16][256]
+    hipLaunchKernelGGL(ltae_fold_bwd1_kernel, dim3(NH + NH * DV), dim3(64), 0, st, gs0, pe, SP, BT);
+    C2S_CHECK_LAUNCH("ltae_fold_bwd1");
+    hipLaunchKernelGGL(ltae_fold_bwd2_kernel, dim3(DM), dim3(64), 0, st, Wc, bc, qwk, gU, SP, gWc_attn, gbc_attn, gq, gWc, gbc, C,
+                       (acc_mask >> 3) & 1, (acc_mask >> 4) & 1);
+    C2S_CHECK_LAUNCH("ltae_fold_bwd2");
+    hipLaunchKernelGGL(ltae_fold_bwd3_kernel, dim3(NH * DK), dim3(64), 0, st, Q, Wk, bk, gq, SP, gQ, gWk, gbk, acc_mask & 1,
+                       (acc_mask >> 1) & 1, (acc_mask >> 2) & 1);
+    C2S_CHECK_LAUNCH("ltae_fold_bwd3");
     return C2S_OK;
 }
 

@@ -640,10 +640,12 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
                  prefix + ".attention_head.fc1_k.bias", prefix + ".inconv.weight", prefix + ".inconv.bias"]
         sinks = [ctx.grad_sink(nme) for nme in names]
         acc_mask = sum((1 << i) for i, (_, acc) in enumerate(sinks) if acc)
+        fbw = ctx.ws.get("ltae_fold_bwd", lib().c2s_ltae_fold_bwd_workspace_floats())
         check(lib().c2s_ltae_fold_bwd(Q.data_ptr(), Wk.data_ptr(), bk.data_ptr(), Wc3.data_ptr(), bc.data_ptr(), pe.data_ptr(),
                                       qwk.data_ptr(), gU.data_ptr(), gs0.data_ptr(),
                                       gWc.data_ptr() if emb is not None else None, gbc.data_ptr() if emb is not None else None,
-                                      *[t.data_ptr() for t, _ in sinks], B * T, Cc, acc_mask, _stream()), "ltae_fold_bwd")
+                                      *[t.data_ptr() for t, _ in sinks], B * T, Cc, acc_mask, fbw.data_ptr(), fbw.numel(),
+                                      _stream()), "ltae_fold_bwd")
         tape.add_grad(x5, gx)
 
     tape.record(bwd)

@@ -261,7 +261,9 @@ int c2s_ltae_fold_fwd(const float* Q, const float* Wk, const float* bk, const fl
                       float* U, float* s0, float* qwk, int BT, int C, void* stream);
 int c2s_ltae_fold_bwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc, const float* pe,
                       const float* qwk, const float* gU, const float* gs0, const float* gWc_attn, const float* gbc_attn,
-                      float* gQ, float* gWk, float* gbk, float* gWc, float* gbc, int BT, int C, int acc_mask, void* stream);
+                      float* gQ, float* gWk, float* gbk, float* gWc, float* gbc, int BT, int C, int acc_mask,
+                      float* workspace, size_t ws_floats, void* stream);
+size_t c2s_ltae_fold_bwd_workspace_floats(void);
 
 /* L-TAE tail (tae.py:442-449,486-488).  Linear(256,C') is a 1x1 convolution on the NCHW embedding
  * (c2s_conv_igemm), BatchNorm1d over P is c2s_norm_* with kind BATCH; the two pieces below are the rest:
