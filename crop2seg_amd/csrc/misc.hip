@@ -73,61 +73,70 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
 }
 
 // data gradient, gather form: input pixel j receives from the padded positions that reflect onto it
-// (j itself; -1 if j == 1; n if j == n-2) through every tap whose output index is integral and in range
+// (j itself; -1 if j == 1; n if j == n-2) through every tap whose output index is integral and in range.
+// Per dimension that is a short list of (output index, tap) pairs -- at most 3 for 3x3/s1 plus one mirrored, at most
+// 2 + 2 for 4x4/s2 -- built once per thread without branches in the accumulation loop (invalid slots point at output 0
+// with weight 0); the 2-D gradient is the product of the two lists.  Four adjacent pixels of a row per thread (float4
+// store; the row list is shared).
+template <int K, int S>
+__device__ __forceinline__ void dw_pairs(int j, int n_in, int n_out, int pad, bool rf, int (&o)[4], int (&k)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = 0; k[i] = -1; }
+    int cnt = 0;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        const int t = j + pad - kk;
+        const bool ok = t >= 0 && (t % S) == 0 && t / S < n_out;
+        if (ok && cnt < 4) { o[cnt] = t / S; k[cnt] = kk; ++cnt; }
+    }
+    const int qm = (rf && j == 1) ? -1 : ((rf && j == n_in - 2) ? n_in : -2);
+    if (qm != -2) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int t = qm + pad - kk;
+            const bool ok = t >= 0 && (t % S) == 0 && t / S < n_out;
+            if (ok && cnt < 4) { o[cnt] = t / S; k[cnt] = kk; ++cnt; }
+        }
+    }
+}
+
 template <int K, int S>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w,
                                                        float* __restrict__ gin, const int* __restrict__ valid, int C,
                                                        int Hin, int Win, int pad, int reflect) {
+    __shared__ float ws[K * K + 1];
     const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    if (threadIdx.x < K * K) ws[threadIdx.x] = w[(size_t)c * K * K + threadIdx.x];
+    if (threadIdx.x == K * K) ws[K * K] = 0.f;                      // weight of an empty slot
+    __syncthreads();
+    const int W4 = Win >> 2;                                          // host guarantees Win % 4 == 0
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Hin * Win) return;
-    float* gp_in = gin + (size_t)plane * Hin * Win;
-    if (valid != nullptr && valid[n] == 0) { gp_in[e] = 0.f; return; }
+    if (e >= Hin * W4) return;
+    const int jy = e / W4, jx0 = (e - jy * W4) * 4;
+    float* gp_in = gin + (size_t)plane * Hin * Win + (size_t)jy * Win + jx0;
+    if (valid != nullptr && valid[n] == 0) { *reinterpret_cast<f32x4*>(gp_in) = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
-    const int jy = e / Win, jx = e - jy * Win;
-    float wk[K * K];
-#pragma unroll
-    for (int k = 0; k < K * K; ++k) wk[k] = w[(size_t)c * K * K + k];
     const float* gp = gout + (size_t)plane * Ho * Wo;
     const bool rf = reflect && pad >= 1;
-    // per dimension: for each tap k the (up to 2 regular+mirrored) output indices
-    float acc = 0.f;
+    int oy[4], ky[4];
+    dw_pairs<K, S>(jy, Hin, Ho, pad, rf, oy, ky);
+    f32x4 res;
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        // candidates qy in {jy, mirror}: ty = qy + pad - ky must be >= 0, divisible by S, < Ho*S
-        int oys[2];
-        int ny = 0;
-        {
-            const int ty = jy + pad - ky;
-            if (ty >= 0 && ty % S == 0 && ty / S < Ho) oys[ny++] = ty / S;
-            int qm = -2;
-            if (rf && jy == 1) qm = -1;
-            if (rf && jy == Hin - 2) qm = Hin;
-            if (qm != -2) {
-                const int tm = qm + pad - ky;
-                if (tm >= 0 && tm % S == 0 && tm / S < Ho) oys[ny++] = tm / S;
+    for (int u = 0; u < 4; ++u) {
+        int ox[4], kx[4];
+        dw_pairs<K, S>(jx0 + u, Win, Wo, pad, rf, ox, kx);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int wi = (ky[a] >= 0 && kx[bb] >= 0) ? ky[a] * K + kx[bb] : K * K;
+                acc = fmaf(ws[wi], gp[oy[a] * Wo + ox[bb]], acc);
             }
         }
-        if (ny == 0) continue;
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            int oxs[2];
-            int nx = 0;
-            const int tx = jx + pad - kx;
-            if (tx >= 0 && tx % S == 0 && tx / S < Wo) oxs[nx++] = tx / S;
-            int qm = -2;
-            if (rf && jx == 1) qm = -1;
-            if (rf && jx == Win - 2) qm = Win;
-            if (qm != -2) {
-                const int tm = qm + pad - kx;
-                if (tm >= 0 && tm % S == 0 && tm / S < Wo) oxs[nx++] = tm / S;
-            }
-            const float wv = wk[ky * K + kx];
-            for (int a = 0; a < ny; ++a)
-                for (int bb = 0; bb < nx; ++bb) acc = fmaf(wv, gp[oys[a] * Wo + oxs[bb]], acc);
-        }
+        res[u] = acc;
     }
-    gp_in[e] = acc;
+    *reinterpret_cast<f32x4*>(gp_in) = res;
 }
 
 // partial[n][c][k] : one workgroup per (n, c)
@@ -311,7 +320,8 @@ extern "C" int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, c
                                 int Win, int K, int S, int pad, int pad_mode, void* stream) {
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(gout && w && gin, "dwconv_dgrad: null pointer");
-    const dim3 grid(cdiv(Hin * Win, 256), N * C);
+    C2S_REQUIRE(Win % 4 == 0, "dwconv_dgrad: the plane width must be a multiple of 4");
+    const dim3 grid(cdiv(Hin * (Win / 4), 256), N * C);
     if (K == 3)
         hipLaunchKernelGGL((dw_dgrad_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, gout, w, gin, valid, C, Hin, Win,
                            pad, pad_mode == C2S_PAD_REFLECT);
