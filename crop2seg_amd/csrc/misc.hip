@@ -100,7 +100,7 @@ __device__ __forceinline__ void dw_pairs(int j, int n_in, int n_out, int pad, bo
     }
 }
 
-template <int K, int S>
+template <int K, int S, int PX>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w,
                                                        float* __restrict__ gin, const int* __restrict__ valid, int C,
                                                        int Hin, int Win, int pad, int reflect) {
@@ -109,20 +109,60 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
     if (threadIdx.x < K * K) ws[threadIdx.x] = w[(size_t)c * K * K + threadIdx.x];
     if (threadIdx.x == K * K) ws[K * K] = 0.f;                      // weight of an empty slot
     __syncthreads();
-    const int W4 = Win >> 2;                                          // host guarantees Win % 4 == 0
+    const int W4 = Win / PX;                                          // PX = 4 needs Win % 4 == 0 (host dispatch)
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= Hin * W4) return;
-    const int jy = e / W4, jx0 = (e - jy * W4) * 4;
+    const int jy = e / W4, jx0 = (e - jy * W4) * PX;
     float* gp_in = gin + (size_t)plane * Hin * Win + (size_t)jy * Win + jx0;
-    if (valid != nullptr && valid[n] == 0) { *reinterpret_cast<f32x4*>(gp_in) = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
+    if (valid != nullptr && valid[n] == 0) {
+#pragma unroll
+        for (int u = 0; u < PX; ++u) gp_in[u] = 0.f;
+        return;
+    }
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
     const float* gp = gout + (size_t)plane * Ho * Wo;
     const bool rf = reflect && pad >= 1;
+    // interior fast path (no border, no reflection fold): a plain stencil over 3 (3x3) / 2 (4x4 s2) rows of gout
+    if (PX == 4 && pad == 1 && jy >= 2 && jy <= Hin - 3 && jx0 >= 4 && jx0 + 8 <= Win) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (K == 3 && S == 1) {
+#pragma unroll
+            for (int kyy = 0; kyy < 3; ++kyy) {
+                const float* row = gp + (size_t)(jy + 1 - kyy) * Wo + jx0 - 1;      // columns jx0-1 .. jx0+4
+                float g[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) g[i] = row[i];
+#pragma unroll
+                for (int kxx = 0; kxx < 3; ++kxx) {
+                    const float wv = ws[kyy * 3 + kxx];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r[u] = fmaf(wv, g[u + 2 - kxx], r[u]);   // column x + 1 - kx
+                }
+            }
+        } else {
+            const int py = (jy + 1) & 1;                       // taps ky = py, py + 2
+            const int oyb = (jy + 1 - py) >> 1;                // output row of tap py; tap py + 2 reads the row above
+            const int oxb = jx0 >> 1;                          // gout columns oxb-1 .. oxb+2 serve the four pixels
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float* row = gp + (size_t)(oyb - a) * Wo + oxb - 1;
+                const float g0 = row[0], g1 = row[1], g2 = row[2], g3 = row[3];
+                const float* wr = ws + (py + 2 * a) * 4;
+                // even pixel x: taps kx = 1 (column x/2), 3 (x/2 - 1); odd pixel: taps 0 (column (x+1)/2), 2 ((x-1)/2)
+                r[0] = fmaf(wr[1], g1, fmaf(wr[3], g0, r[0]));
+                r[1] = fmaf(wr[0], g2, fmaf(wr[2], g1, r[1]));
+                r[2] = fmaf(wr[1], g2, fmaf(wr[3], g1, r[2]));
+                r[3] = fmaf(wr[0], g3, fmaf(wr[2], g2, r[3]));
+            }
+        }
+        *reinterpret_cast<f32x4*>(gp_in) = r;
+        return;
+    }
     int oy[4], ky[4];
     dw_pairs<K, S>(jy, Hin, Ho, pad, rf, oy, ky);
-    f32x4 res;
+    float res[PX];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PX; ++u) {
         int ox[4], kx[4];
         dw_pairs<K, S>(jx0 + u, Win, Wo, pad, rf, ox, kx);
         float acc = 0.f;
@@ -136,7 +176,8 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
         }
         res[u] = acc;
     }
-    *reinterpret_cast<f32x4*>(gp_in) = res;
+#pragma unroll
+    for (int u = 0; u < PX; ++u) gp_in[u] = res[u];
 }
 
 // partial[n][c][k] : one workgroup per (n, c)
@@ -320,14 +361,17 @@ extern "C" int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, c
                                 int Win, int K, int S, int pad, int pad_mode, void* stream) {
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(gout && w && gin, "dwconv_dgrad: null pointer");
-    C2S_REQUIRE(Win % 4 == 0, "dwconv_dgrad: the plane width must be a multiple of 4");
-    const dim3 grid(cdiv(Hin * (Win / 4), 256), N * C);
-    if (K == 3)
-        hipLaunchKernelGGL((dw_dgrad_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, gout, w, gin, valid, C, Hin, Win,
-                           pad, pad_mode == C2S_PAD_REFLECT);
-    else
-        hipLaunchKernelGGL((dw_dgrad_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, gout, w, gin, valid, C, Hin, Win,
-                           pad, pad_mode == C2S_PAD_REFLECT);
+    const bool reflect = pad_mode == C2S_PAD_REFLECT;
+    hipStream_t st = (hipStream_t)stream;
+    if (Win % 4 == 0) {
+        const dim3 grid(cdiv(Hin * (Win / 4), 256), N * C);
+        if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
+        else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
+    } else {
+        const dim3 grid(cdiv(Hin * Win, 256), N * C);
+        if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 1>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
+        else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 1>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
+    }
     C2S_CHECK_LAUNCH("dwconv_dgrad");
     return C2S_OK;
 }
