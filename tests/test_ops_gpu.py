@@ -440,3 +440,32 @@ def test_conv3x3_bf16x3_fwd_bwd(case):
     if C1:
         assert rel(ctx.tape.grads[sd.data_ptr()][keep.cuda()], s2.grad[keep]) < 5e-5
     assert rel(ctx.g["w"], w.grad) < 5e-5
+
+
+def test_pack_plan_matches_individual_packs():
+    """From the second step on all weight packs (tap-major and Winograd) run as one launch from a job table built during
+    the first step: the convolution results must be bit-identical to the individually packed ones."""
+    E, L = _engine()
+    g = torch.Generator().manual_seed(23)
+    dev = torch.device("cuda")
+    params = {"w3": (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev), "b3": torch.randn(64, generator=g).to(dev),
+              "w4": (torch.randn(64, 64, 4, 4, generator=g) / 32).to(dev), "b4": torch.randn(64, generator=g).to(dev)}
+    x = torch.randn(2, 64, 32, 32, generator=g).to(dev)
+    ws = E.Workspace(dev)
+
+    def run():
+        grads = {k: torch.zeros_like(v) for k, v in params.items()}
+        ctx = E.Ctx(params, {}, grads, ws, True, E.Tape())
+        y3 = E.conv2d(ctx, [x], "w3", "b3", 3, 1, 1, L.PAD_REFLECT, None)          # Winograd forward + data gradient packs
+        y4 = E.conv2d(ctx, [y3], "w4", "b4", 4, 2, 1, L.PAD_REFLECT, None)         # direct forward, transposed data gradient packs
+        ctx.tape.grads[y4.data_ptr()] = torch.ones_like(y4)
+        ctx.tape.backward()
+        return y3.clone(), y4.clone(), ctx.tape.grads[x.data_ptr()].clone(), grads["w3"].clone(), grads["w4"].clone()
+
+    first = run()
+    assert ws.pack_plan is None and len(ws.pack_record) >= 4
+    ws.finalize_pack_plan()
+    assert ws.pack_plan is not None and ws.pack_plan["njobs"] >= 4
+    second = run()
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
