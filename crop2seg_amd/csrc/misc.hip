@@ -39,37 +39,75 @@ __global__ __launch_bounds__(256) void frame_flags_kernel(const float* __restric
 
 // ---------------------------------------------------------------- depthwise conv (conv.py:18-24)
 // HBM-bound.  grid = (pixel blocks, N*C planes); (K,S) are template parameters so the tap loops unroll and the
-// K*K weights of the plane sit in registers.
-template <int K, int S>
+// K*K weights of the plane sit in registers.  A thread owns PX adjacent outputs of a row: per input row they read one
+// span of (PX-1)*S + K columns starting at ox0*S - pad, which for interior spans (pad == 1, PX == 4) is one scalar, one
+// or two aligned float4s and one scalar instead of PX*K dwords; border spans go element-wise through the padding rule.
+template <int K, int S, int PX>
+__device__ __forceinline__ void dw_load_span(const float* __restrict__ row, int xs, int Win, bool reflect, bool fast,
+                                             float (&v)[(PX - 1) * S + K]) {
+    constexpr int SP = (PX - 1) * S + K;
+    if (fast) {                                          // xs + 1 is a multiple of 4 and the whole span is in range
+        v[0] = row[xs];
+#pragma unroll
+        for (int q = 0; q < (SP - 2) / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(row + xs + 1 + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[1 + 4 * q + i] = t[i];
+        }
+        v[SP - 1] = row[xs + SP - 1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            int gx = xs + i;
+            bool ok = true;
+            if (reflect) gx = reflect_idx(gx, Win); else ok = gx >= 0 && gx < Win;
+            const float t = row[ok ? gx : 0];
+            v[i] = ok ? t : 0.f;
+        }
+    }
+}
+
+template <int K, int S, int PX>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                      float* __restrict__ out, const int* __restrict__ valid, int C,
                                                      int Hin, int Win, int pad, int reflect) {
+    constexpr int SP = (PX - 1) * S + K;
     const int plane = blockIdx.y, c = plane % C, n = plane / C;
     if (valid != nullptr && valid[n] == 0) return;
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    const int W4 = Wo / PX;                                          // PX = 4 needs Wo % 4 == 0 (host dispatch)
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Ho * Wo) return;
-    const int oy = e / Wo, ox = e - oy * Wo;
+    if (e >= Ho * W4) return;
+    const int oy = e / W4, ox0 = (e - oy * W4) * PX;
     float wk[K * K];
 #pragma unroll
     for (int k = 0; k < K * K; ++k) wk[k] = w[(size_t)c * K * K + k];
     const float* ip = in + (size_t)plane * Hin * Win;
-    float acc = 0.f;
+    const int xs = ox0 * S - pad;
+    const bool fast = PX == 4 && pad == 1 && xs >= 0 && xs + SP <= Win;
+    float acc[PX];
+#pragma unroll
+    for (int u = 0; u < PX; ++u) acc[u] = 0.f;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         int gy = oy * S - pad + ky;
         bool oky = true;
         if (reflect) gy = reflect_idx(gy, Hin); else oky = gy >= 0 && gy < Hin;
+        if (!oky) continue;                                          // a zero-padded row adds nothing
+        float v[SP];
+        dw_load_span<K, S, PX>(ip + (size_t)gy * Win, xs, Win, reflect != 0, fast, v);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            int gx = ox * S - pad + kx;
-            bool ok = oky;
-            if (reflect) gx = reflect_idx(gx, Win); else ok = ok && gx >= 0 && gx < Win;
-            const float v = ip[ok ? gy * Win + gx : 0];
-            acc = fmaf(wk[ky * K + kx], ok ? v : 0.f, acc);
-        }
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int u = 0; u < PX; ++u) acc[u] = fmaf(wk[ky * K + kx], v[u * S + kx], acc[u]);
     }
-    out[(size_t)plane * Ho * Wo + e] = acc;
+    float* op = out + (size_t)plane * Ho * Wo + (size_t)oy * Wo + ox0;
+    if constexpr (PX == 4) {
+        const f32x4 r = {acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(op) = r;
+    } else {
+        op[0] = acc[0];
+    }
 }
 
 // data gradient, gather form: input pixel j receives from the padded positions that reflect onto it
@@ -181,35 +219,45 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
 }
 
 // partial[n][c][k] : one workgroup per (n, c)
-template <int K, int S>
+template <int K, int S, int PX>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                        float* __restrict__ partial, const int* __restrict__ valid, int C,
                                                        int Hin, int Win, int pad, int reflect) {
+    constexpr int SP = (PX - 1) * S + K;
     __shared__ float red[4][K * K];
     const int n = blockIdx.x / C;
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
+    const int W4 = Wo / PX;                                          // PX = 4 needs Wo % 4 == 0 (host dispatch)
     float acc[K * K];
 #pragma unroll
     for (int k = 0; k < K * K; ++k) acc[k] = 0.f;
     if (valid == nullptr || valid[n] != 0) {
         const float* ip = in + (size_t)blockIdx.x * Hin * Win;
         const float* gp = gout + (size_t)blockIdx.x * Ho * Wo;
-        for (int e = threadIdx.x; e < Ho * Wo; e += 256) {
-            const int oy = e / Wo, ox = e - oy * Wo;
-            const float g = gp[e];
+        for (int e = threadIdx.x; e < Ho * W4; e += 256) {
+            const int oy = e / W4, ox0 = (e - oy * W4) * PX;
+            float g[PX];
+            if constexpr (PX == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(gp + (size_t)oy * Wo + ox0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = t[u];
+            } else {
+                g[0] = gp[(size_t)oy * Wo + ox0];
+            }
+            const int xs = ox0 * S - pad;
+            const bool fast = PX == 4 && pad == 1 && xs >= 0 && xs + SP <= Win;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 int gy = oy * S - pad + ky;
                 bool oky = true;
                 if (reflect) gy = reflect_idx(gy, Hin); else oky = gy >= 0 && gy < Hin;
+                if (!oky) continue;
+                float v[SP];
+                dw_load_span<K, S, PX>(ip + (size_t)gy * Win, xs, Win, reflect != 0, fast, v);
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    int gx = ox * S - pad + kx;
-                    bool ok = oky;
-                    if (reflect) gx = reflect_idx(gx, Win); else ok = ok && gx >= 0 && gx < Win;
-                    const float v = ip[ok ? gy * Win + gx : 0];
-                    acc[ky * K + kx] = fmaf(g, ok ? v : 0.f, acc[ky * K + kx]);
-                }
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int u = 0; u < PX; ++u) acc[ky * K + kx] = fmaf(g[u], v[u * S + kx], acc[ky * K + kx]);
             }
         }
     }
@@ -349,13 +397,17 @@ extern "C" int c2s_dwconv_fwd(const float* in, const float* w, float* out, const
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(in && w && out, "dwconv_fwd: null pointer");
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
-    const dim3 grid(cdiv(Ho * Wo, 256), N * C);
-    if (K == 3)
-        hipLaunchKernelGGL((dw_fwd_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, w, out, valid, C, Hin, Win, pad,
-                           pad_mode == C2S_PAD_REFLECT);
-    else
-        hipLaunchKernelGGL((dw_fwd_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, in, w, out, valid, C, Hin, Win, pad,
-                           pad_mode == C2S_PAD_REFLECT);
+    const bool reflect = pad_mode == C2S_PAD_REFLECT;
+    hipStream_t st = (hipStream_t)stream;
+    if (Wo % 4 == 0) {
+        const dim3 grid(cdiv(Ho * (Wo / 4), 256), N * C);
+        if (K == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, 1, 4>), grid, dim3(256), 0, st, in, w, out, valid, C, Hin, Win, pad, reflect);
+        else hipLaunchKernelGGL((dw_fwd_kernel<4, 2, 4>), grid, dim3(256), 0, st, in, w, out, valid, C, Hin, Win, pad, reflect);
+    } else {
+        const dim3 grid(cdiv(Ho * Wo, 256), N * C);
+        if (K == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, 1, 1>), grid, dim3(256), 0, st, in, w, out, valid, C, Hin, Win, pad, reflect);
+        else hipLaunchKernelGGL((dw_fwd_kernel<4, 2, 1>), grid, dim3(256), 0, st, in, w, out, valid, C, Hin, Win, pad, reflect);
+    }
     C2S_CHECK_LAUNCH("dwconv_fwd");
     return C2S_OK;
 }
@@ -384,12 +436,16 @@ extern "C" int c2s_dwconv_wgrad(const float* in, const float* gout, float* parti
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(in && gout && partial && gw, "dwconv_wgrad: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (K == 3)
-        hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(N * C), dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad,
-                           pad_mode == C2S_PAD_REFLECT);
-    else
-        hipLaunchKernelGGL((dw_wgrad_kernel<4, 2>), dim3(N * C), dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad,
-                           pad_mode == C2S_PAD_REFLECT);
+    const bool reflect = pad_mode == C2S_PAD_REFLECT;
+    const int Wo = (Win + 2 * pad - K) / S + 1;
+    const dim3 grid(N * C);
+    if (Wo % 4 == 0) {
+        if (K == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, 4>), grid, dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad, reflect);
+        else hipLaunchKernelGGL((dw_wgrad_kernel<4, 2, 4>), grid, dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad, reflect);
+    } else {
+        if (K == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, 1>), grid, dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad, reflect);
+        else hipLaunchKernelGGL((dw_wgrad_kernel<4, 2, 1>), grid, dim3(256), 0, st, in, gout, partial, valid, C, Hin, Win, pad, reflect);
+    }
     C2S_CHECK_LAUNCH("dwconv_wgrad");
     hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(C * K * K), dim3(64), 0, st, partial, gw, N, C * K * K);
     C2S_CHECK_LAUNCH("dwconv_wgrad_reduce");

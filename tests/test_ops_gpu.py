@@ -125,11 +125,12 @@ def test_conv_concat_sources():
     assert rel(ctx.g["w"], w.grad) < 5e-6
 
 
+@pytest.mark.parametrize("hw", [16, 40, 6])          # 40: float4 interior spans; 6: one output per thread (Wo % 4 != 0)
 @pytest.mark.parametrize("K,S", [(3, 1), (4, 2)])
-def test_depthwise_fwd_bwd(K, S):
+def test_depthwise_fwd_bwd(K, S, hw):
     E, L = _engine()
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(3, 64, 16, 16, generator=g, requires_grad=True)
+    x = torch.randn(3, 64, hw, hw + (8 if hw == 40 else 0), generator=g, requires_grad=True)
     w = torch.randn(64, 1, K, K, generator=g, requires_grad=True)
     ref = O.conv2d(x, w, None, S, 1, "reflect", groups=64)
     gout = torch.randn(ref.shape, generator=g)
