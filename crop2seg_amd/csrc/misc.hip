@@ -40,21 +40,26 @@ __global__ __launch_bounds__(256) void frame_flags_kernel(const float* __restric
 // ---------------------------------------------------------------- depthwise conv (conv.py:18-24)
 // HBM-bound.  grid = (pixel blocks, N*C planes); (K,S) are template parameters so the tap loops unroll and the
 // K*K weights of the plane sit in registers.  A thread owns PX adjacent outputs of a row: per input row they read one
-// span of (PX-1)*S + K columns starting at ox0*S - pad, which for interior spans (pad == 1, PX == 4) is one scalar, one
-// or two aligned float4s and one scalar instead of PX*K dwords; border spans go element-wise through the padding rule.
+// span of (PX-1)*S + K columns starting at ox0*S - pad, which (pad == 1, PX == 4) is one scalar, one or two aligned
+// float4s and one scalar instead of PX*K dwords.
 template <int K, int S, int PX>
 __device__ __forceinline__ void dw_load_span(const float* __restrict__ row, int xs, int Win, bool reflect, bool fast,
                                              float (&v)[(PX - 1) * S + K]) {
     constexpr int SP = (PX - 1) * S + K;
-    if (fast) {                                          // xs + 1 is a multiple of 4 and the whole span is in range
-        v[0] = row[xs];
+    if constexpr (PX == 4) {
+        // pad == 1, Win % 4 == 0: xs + 1 is a multiple of 4, the middle of the span is always in range and only its two
+        // end columns can fall on the padding (-1 -> 1, Win -> Win - 2 when reflecting, else zero) -- no divergent path
+        (void)fast;
+        const int xl = xs >= 0 ? xs : 1, xr = xs + SP - 1 < Win ? xs + SP - 1 : Win - 2;
+        const float tl = row[xl], tr = row[xr];
+        v[0] = (xs >= 0 || reflect) ? tl : 0.f;
 #pragma unroll
         for (int q = 0; q < (SP - 2) / 4; ++q) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(row + xs + 1 + 4 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[1 + 4 * q + i] = t[i];
         }
-        v[SP - 1] = row[xs + SP - 1];
+        v[SP - 1] = (xs + SP - 1 < Win || reflect) ? tr : 0.f;
     } else {
 #pragma unroll
         for (int i = 0; i < SP; ++i) {
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     for (int k = 0; k < K * K; ++k) wk[k] = w[(size_t)c * K * K + k];
     const float* ip = in + (size_t)plane * Hin * Win;
     const int xs = ox0 * S - pad;
-    const bool fast = PX == 4 && pad == 1 && xs >= 0 && xs + SP <= Win;
+    const bool fast = false;
     float acc[PX];
 #pragma unroll
     for (int u = 0; u < PX; ++u) acc[u] = 0.f;
@@ -160,37 +165,60 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
     const int Ho = (Hin + 2 * pad - K) / S + 1, Wo = (Win + 2 * pad - K) / S + 1;
     const float* gp = gout + (size_t)plane * Ho * Wo;
     const bool rf = reflect && pad >= 1;
-    // interior fast path (no border, no reflection fold): a plain stencil over 3 (3x3) / 2 (4x4 s2) rows of gout
-    if (PX == 4 && pad == 1 && jy >= 2 && jy <= Hin - 3 && jx0 >= 4 && jx0 + 8 <= Win) {
+    // PX == 4 (host: pad == 1, Win % 4 == 0, Win >= 8, Hin >= 4, Hin even for 4x4/s2): a plain stencil over gout with the
+    // border handled in place -- columns/rows off the plane are dropped and the reflection fold adds one tap at input
+    // columns 1 and Win - 2 and one (row, tap) slot at input rows 1 and Hin - 2; no divergent general path.
+    if constexpr (PX == 4) {
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        const bool fl = rf && jx0 == 0, fr = rf && jx0 + 4 == Win;
+        int rows[3], kys[3];
         if constexpr (K == 3 && S == 1) {
-#pragma unroll
-            for (int kyy = 0; kyy < 3; ++kyy) {
-                const float* row = gp + (size_t)(jy + 1 - kyy) * Wo + jx0 - 1;      // columns jx0-1 .. jx0+4
-                float g[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) g[i] = row[i];
-#pragma unroll
-                for (int kxx = 0; kxx < 3; ++kxx) {
-                    const float wv = ws[kyy * 3 + kxx];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) r[u] = fmaf(wv, g[u + 2 - kxx], r[u]);   // column x + 1 - kx
-                }
-            }
+            rows[0] = jy + 1; kys[0] = rows[0] < Ho ? 0 : -1;
+            rows[1] = jy;     kys[1] = 1;
+            rows[2] = jy - 1; kys[2] = rows[2] >= 0 ? 2 : -1;
         } else {
-            const int py = (jy + 1) & 1;                       // taps ky = py, py + 2
-            const int oyb = (jy + 1 - py) >> 1;                // output row of tap py; tap py + 2 reads the row above
-            const int oxb = jx0 >> 1;                          // gout columns oxb-1 .. oxb+2 serve the four pixels
+            const int py = (jy + 1) & 1;                       // taps ky = py (row oyb), py + 2 (row oyb - 1)
+            const int oyb = (jy + 1 - py) >> 1;
+            rows[0] = oyb;     kys[0] = oyb < Ho ? py : -1;
+            rows[1] = oyb - 1; kys[1] = oyb >= 1 ? py + 2 : -1;
+            rows[2] = 0;       kys[2] = -1;
+        }
+        int xrow = -1, xky = 0;                                // the reflected slot: padded row -1 folds onto 1, Hin onto Hin-2
+        if (rf && jy == 1) { xrow = 0; xky = 0; }
+        if (rf && jy == Hin - 2) { xrow = Ho - 1; xky = K - 1; }
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const float* row = gp + (size_t)(oyb - a) * Wo + oxb - 1;
-                const float g0 = row[0], g1 = row[1], g2 = row[2], g3 = row[3];
-                const float* wr = ws + (py + 2 * a) * 4;
+        for (int a = 0; a < 4; ++a) {
+            int rw, kyv;
+            if (a < 3) { rw = rows[a]; kyv = kys[a]; } else { rw = xrow; kyv = xrow >= 0 ? xky : -1; }
+            if (K == 4 && a == 2) continue;
+            if (kyv < 0) continue;
+            const float* wr = ws + kyv * K;
+            if constexpr (K == 3 && S == 1) {
+                const float* row = gp + (size_t)rw * Wo + jx0;                      // columns jx0-1 .. jx0+4
+                float g[6];
+                const float t0 = row[jx0 > 0 ? -1 : 0], t5 = row[jx0 + 4 < Wo ? 4 : 3];
+                g[0] = jx0 > 0 ? t0 : 0.f;
+                const f32x4 m = *reinterpret_cast<const f32x4*>(row);
+                g[1] = m[0]; g[2] = m[1]; g[3] = m[2]; g[4] = m[3];
+                g[5] = jx0 + 4 < Wo ? t5 : 0.f;
+#pragma unroll
+                for (int kxx = 0; kxx < 3; ++kxx)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r[u] = fmaf(wr[kxx], g[u + 2 - kxx], r[u]);   // column x + 1 - kx
+                if (fl) r[1] = fmaf(wr[0], g[1], r[1]);                             // padded column -1 = column 1, tap 0 of output 0
+                if (fr) r[2] = fmaf(wr[2], g[4], r[2]);                             // padded column Win = column Win-2, tap 2
+            } else {
+                const int oxb = jx0 >> 1;                      // gout columns oxb-1 .. oxb+2 serve the four pixels
+                const float* row = gp + (size_t)rw * Wo + oxb;
+                const float t0 = row[oxb > 0 ? -1 : 0], t3 = row[oxb + 2 < Wo ? 2 : 1];
+                const float g0 = oxb > 0 ? t0 : 0.f, g1 = row[0], g2 = row[1], g3 = oxb + 2 < Wo ? t3 : 0.f;
                 // even pixel x: taps kx = 1 (column x/2), 3 (x/2 - 1); odd pixel: taps 0 (column (x+1)/2), 2 ((x-1)/2)
                 r[0] = fmaf(wr[1], g1, fmaf(wr[3], g0, r[0]));
                 r[1] = fmaf(wr[0], g2, fmaf(wr[2], g1, r[1]));
                 r[2] = fmaf(wr[1], g2, fmaf(wr[3], g1, r[2]));
                 r[3] = fmaf(wr[0], g3, fmaf(wr[2], g2, r[3]));
+                if (fl) r[1] = fmaf(wr[0], g1, r[1]);                               // padded column -1: tap 0 of output 0
+                if (fr) r[2] = fmaf(wr[3], g2, r[2]);                               // padded column Win: tap 3 of output Wo-1
             }
         }
         *reinterpret_cast<f32x4*>(gp_in) = r;
@@ -245,7 +273,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
                 g[0] = gp[(size_t)oy * Wo + ox0];
             }
             const int xs = ox0 * S - pad;
-            const bool fast = PX == 4 && pad == 1 && xs >= 0 && xs + SP <= Win;
+            const bool fast = false;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 int gy = oy * S - pad + ky;
@@ -418,7 +446,7 @@ extern "C" int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, c
     C2S_REQUIRE(gout && w && gin, "dwconv_dgrad: null pointer");
     const bool reflect = pad_mode == C2S_PAD_REFLECT;
     hipStream_t st = (hipStream_t)stream;
-    if (Win % 4 == 0) {
+    if (Win % 4 == 0 && Win >= 8 && Hin >= 4 && (K == 3 || Hin % 2 == 0)) {
         const dim3 grid(cdiv(Hin * (Win / 4), 256), N * C);
         if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
         else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
