@@ -487,16 +487,14 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
     row_ab = torch.empty(N * Cc * 3, device=x.device, dtype=torch.float32)   # per row: (scale, beta, mean)
     nws = lib().c2s_norm_workspace_floats(C.byref(d))
     ws = ctx.ws.get("norm", nws)
-    check(lib().c2s_norm_stats(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
-                               gstats.data_ptr(), row_ab.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(valid), _stream()),
-          "norm_stats")
+    y = torch.empty_like(x)
+    check(lib().c2s_norm_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
+                             gstats.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(), int(relu),
+                             ws.data_ptr(), ws.numel(), _ptr(valid), float(pad_value), _stream()), "norm_fwd")
     if batch and ctx.training:
         nbt = ctx.b.get(prefix + ".num_batches_tracked")
         if nbt is not None:
             nbt.add_(1)
-    y = torch.empty_like(x)
-    check(lib().c2s_norm_apply(C.byref(d), x.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(), int(relu),
-                               _ptr(valid), float(pad_value), _stream()), "norm_apply")
     if ctx.tape is None:
         return y
     tape = ctx.tape

@@ -172,12 +172,14 @@ int c2s_dwconv_wgrad(const float* in, const float* gout, float* partial, float* 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation + ReLU (+ residual), GroupNorm and train/eval BatchNorm share one set of kernels:
  *   rows = (frame n, channel c), each row = HW contiguous floats.
- *   c2s_norm_stats   : per-(row,segment) mean / M2 (two-pass, wave per segment) -> finalised per group
- *                      into per-row (a, beta, mean)  row_ab[n,c,3]  (y = (x - mean)*a + beta), plus mean/rstd per group.
- *   c2s_norm_apply   : y = relu(a*x+b) (+ residual); rows of padded frames are filled with pad_value.
- *   c2s_norm_bwd     : given g = dL/dy: (1) per-row sums of g' = g*[y>0] and g'*xhat, (2) finalise:
- *                      dgamma, dbeta, dbias (gradient of the bias of the producing convolution) and the
- *                      per-row coefficients of  dx = k1*g' + k2*(x-mean) + k3 , (3) elementwise dx.
+ *   c2s_norm_fwd     : two passes over x: (1) per-(row,segment) mean / M2 (wave per segment); (2) every wave combines
+ *                      the partials of its own group (Chan, double) and writes y = relu((x-mean)*a+beta) (+ residual);
+ *                      rows of padded frames are filled with pad_value.  Left for the backward: per-row
+ *                      (a, beta, mean) in row_ab[n,c,3] and (mean, rstd) per group in group_stats.
+ *   c2s_norm_bwd     : given g = dL/dy, two passes over (x, g): (1) per-(row,segment) sums of g' = g*[y>0] and
+ *                      g'*xhat, (2) every wave derives its row's coefficients of dx = k1*g' + k2*(x-mean) + k3 from the
+ *                      sums of its group and writes dx; then one small launch for dgamma, dbeta and dbias (gradient
+ *                      of the bias of the producing convolution).
  * Replaces nn.GroupNorm(4) + ReLU (conv.py:56-60,85-88), nn.BatchNorm2d + ReLU (conv.py:52-53,380,388),
  * the residual add of conv.py:292,410 and their backward ops.
  * stats layout: group stats [G2][2] = (mean, rstd), G2 = N*groups (GROUP) or C (BATCH).
@@ -192,11 +194,10 @@ typedef struct c2s_norm_desc {
 
 size_t c2s_norm_workspace_floats(const c2s_norm_desc* d);
 /* running_mean/var: BATCH only (may be NULL for GROUP); updated in place when training */
-int c2s_norm_stats(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* group_stats, float* row_ab,
-                   float* workspace, size_t ws_floats, const int* valid, void* stream);
-int c2s_norm_apply(const c2s_norm_desc* d, const float* x, const float* row_ab, const float* residual,
-                   float* y, int relu, const int* valid, float pad_value, void* stream);
+int c2s_norm_fwd(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float* group_stats, float* row_ab,
+                 const float* residual, float* y, int relu, float* workspace, size_t ws_floats, const int* valid,
+                 float pad_value, void* stream);
 /* gx may alias g.  dbias may be NULL.  g_residual_out: if non-NULL receives a copy of g (residual branch) */
 int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float* g, const float* gamma,
                  const float* group_stats, const float* row_ab, int relu, float* gx, float* dgamma,
