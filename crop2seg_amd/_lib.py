@@ -73,7 +73,7 @@ SIGNATURES = {
     "c2s_conv_wgrad": (I, [C.POINTER(WgradDesc), P, P, P, P, SZ, P, P]),
     "c2s_wgrad_reduce": (I, [C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, P]),
     "c2s_dwconv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
-    "c2s_dwconv_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "c2s_dwconv_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "c2s_dwconv_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "c2s_norm_workspace_floats": (SZ, [C.POINTER(NormDesc)]),
     "c2s_norm_fwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, P, P, P, P, I, P, SZ, P, F, P]),

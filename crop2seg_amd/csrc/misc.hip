@@ -146,7 +146,7 @@ __device__ __forceinline__ void dw_pairs(int j, int n_in, int n_out, int pad, bo
 template <int K, int S, int PX>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w,
                                                        float* __restrict__ gin, const int* __restrict__ valid, int C,
-                                                       int Hin, int Win, int pad, int reflect) {
+                                                       int Hin, int Win, int pad, int reflect, int accumulate) {
     __shared__ float ws[K * K + 1];
     const int plane = blockIdx.y, c = plane % C, n = plane / C;
     if (threadIdx.x < K * K) ws[threadIdx.x] = w[(size_t)c * K * K + threadIdx.x];
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
     const int jy = e / W4, jx0 = (e - jy * W4) * PX;
     float* gp_in = gin + (size_t)plane * Hin * Win + (size_t)jy * Win + jx0;
     if (valid != nullptr && valid[n] == 0) {
+        if (accumulate) return;                                      // gin += 0
 #pragma unroll
         for (int u = 0; u < PX; ++u) gp_in[u] = 0.f;
         return;
@@ -221,6 +222,11 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
                 if (fr) r[2] = fmaf(wr[3], g2, r[2]);                               // padded column Win: tap 3 of output Wo-1
             }
         }
+        if (accumulate) {
+            const f32x4 cur = *reinterpret_cast<const f32x4*>(gp_in);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] += cur[u];
+        }
         *reinterpret_cast<f32x4*>(gp_in) = r;
         return;
     }
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
         res[u] = acc;
     }
 #pragma unroll
-    for (int u = 0; u < PX; ++u) gp_in[u] = res[u];
+    for (int u = 0; u < PX; ++u) gp_in[u] = accumulate ? gp_in[u] + res[u] : res[u];
 }
 
 // partial[n][c][k] : one workgroup per (n, c)
@@ -441,19 +447,19 @@ extern "C" int c2s_dwconv_fwd(const float* in, const float* w, float* out, const
 }
 
 extern "C" int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, const int* valid, int N, int C, int Hin,
-                                int Win, int K, int S, int pad, int pad_mode, void* stream) {
+                                int Win, int K, int S, int pad, int pad_mode, int accumulate, void* stream) {
     if (int rc = dw_check(N, C, Hin, Win, K, S, pad, pad_mode)) return rc;
     C2S_REQUIRE(gout && w && gin, "dwconv_dgrad: null pointer");
     const bool reflect = pad_mode == C2S_PAD_REFLECT;
     hipStream_t st = (hipStream_t)stream;
     if (Win % 4 == 0 && Win >= 8 && Hin >= 4 && (K == 3 || Hin % 2 == 0)) {
         const dim3 grid(cdiv(Hin * (Win / 4), 256), N * C);
-        if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
-        else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
+        if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect, accumulate);
+        else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 4>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect, accumulate);
     } else {
         const dim3 grid(cdiv(Hin * Win, 256), N * C);
-        if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 1>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
-        else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 1>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect);
+        if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1, 1>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect, accumulate);
+        else hipLaunchKernelGGL((dw_dgrad_kernel<4, 2, 1>), grid, dim3(256), 0, st, gout, w, gin, valid, C, Hin, Win, pad, reflect, accumulate);
     }
     C2S_CHECK_LAUNCH("dwconv_dgrad");
     return C2S_OK;

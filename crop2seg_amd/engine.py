@@ -457,11 +457,13 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
         check(lib().c2s_dwconv_wgrad(x.data_ptr(), g.data_ptr(), part.data_ptr(), tgt.data_ptr(), _ptr(valid), N, Cc, Hin,
                                      Win, K, S, pad, pad_mode, _stream()), "dwconv_wgrad")
         if acc:
-            gw.add_(tgt)
-        gin = torch.empty_like(x)
+            check(lib().c2s_add_inplace(gw.data_ptr(), tgt.data_ptr(), tgt.numel(), _stream()), "add_inplace")
+        existing = tape.grad_of(x)                      # e.g. the residual branch of the block: accumulate in the kernel
+        gin = existing if existing is not None else torch.empty_like(x)
         check(lib().c2s_dwconv_dgrad(g.data_ptr(), W.data_ptr(), gin.data_ptr(), _ptr(valid), N, Cc, Hin, Win, K, S, pad,
-                                     pad_mode, _stream()), "dwconv_dgrad")
-        tape.add_grad(x, gin)
+                                     pad_mode, 1 if existing is not None else 0, _stream()), "dwconv_dgrad")
+        if existing is None:
+            tape.grads[x.data_ptr()] = gin
 
     tape.record(bwd)
     return out

@@ -163,8 +163,9 @@ int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, float* dst, lo
  * ------------------------------------------------------------------------------------------------ */
 int c2s_dwconv_fwd(const float* in, const float* w, float* out, const int* valid, int N, int C, int Hin, int Win,
                    int K, int S, int pad, int pad_mode, void* stream);
+/* accumulate != 0: gin += the data gradient (the residual branch of the block already left its gradient there) */
 int c2s_dwconv_dgrad(const float* gout, const float* w, float* gin, const int* valid, int N, int C, int Hin, int Win,
-                     int K, int S, int pad, int pad_mode, void* stream);
+                     int K, int S, int pad, int pad_mode, int accumulate, void* stream);
 /* gw[C,K,K] = sum_n ...; `partial` is scratch of N*C*K*K floats */
 int c2s_dwconv_wgrad(const float* in, const float* gout, float* partial, float* gw, const int* valid, int N, int C,
                      int Hin, int Win, int K, int S, int pad, int pad_mode, void* stream);
