@@ -63,6 +63,8 @@ SIGNATURES = {
     "c2s_pack_batch": (I, [P, I, I, P]),
     "c2s_conv_igemm": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "c2s_conv_xpair": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P]),
+    "c2s_conv3x3_smallcin_supported": (I, [C.POINTER(ConvDesc)]),
+    "c2s_conv3x3_smallcin": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P]),
     "c2s_winograd_packed_floats": (SZ, [I, I]),
     "c2s_pack_weights_winograd": (I, [P, P, I, I, I, L, L, C.POINTER(I), P]),
     "c2s_conv3x3_winograd": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P]),

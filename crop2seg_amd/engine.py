@@ -341,7 +341,11 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     else:
         wpk, CoutP = ctx.pack((wname, "fwd"), W, 0, Cin, Cout, KK, Cin * KK, KK, list(range(KK)))
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
-        _igemm(d, s0, s1, wpk, ctx.p[bname] if bname else None, out, valid)
+        if lib().c2s_conv3x3_smallcin_supported(C.byref(d)):      # the first layer
+            check(lib().c2s_conv3x3_smallcin(C.byref(d), s0.data_ptr(), wpk.data_ptr(), _ptr(ctx.p[bname] if bname else None),
+                                             out.data_ptr(), _ptr(valid), _stream()), "conv3x3_smallcin")
+        else:
+            _igemm(d, s0, s1, wpk, ctx.p[bname] if bname else None, out, valid)
     if ctx.tape is None:
         return out
     tape = ctx.tape

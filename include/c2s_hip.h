@@ -93,6 +93,17 @@ int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const float* src1,
                    const float* bias, float* out, const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3x3 stride-1 pad-1 convolution of a few input channels (<= 10: the Sentinel-2 bands of the first layer), same
+ * arithmetic and wpk layout as c2s_conv_igemm, specialised: the 9*Cin x 64 weights of a wave stay in registers, the
+ * padded input patch of an 8x32 tile is staged once, no channel chunking.  c2s_conv3x3_smallcin_supported tells
+ * whether a descriptor qualifies (one source, Hin % 8 == 0, Win % 32 == 0, Cout % 64 == 0, plain placement).
+ * Replaces the first nn.Conv2d of the in_conv block (conv.py:70-80 via utae.py:64-71, timeunet_v1.py, wtae.py).
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_conv3x3_smallcin_supported(const c2s_conv_desc* d);
+int c2s_conv3x3_smallcin(const c2s_conv_desc* d, const float* src, const float* wpk, const float* bias, float* out,
+                         const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Transposed 4x4 stride-2 pad-1 convolution, one output-row parity per launch, both column parities fused:
  *   out[n, o, 2i+py, 2j+px] (+)= bias[o] + sum_{c,ty,tx} in[n, c, i-(1-py)+ty, j-(1-px)+tx] * wpk[px][ty*2+tx][c][o]
  * with py = 1 - d->pad_y.  Descriptor: KH = KW = 2, S = 1, pad_mode = ZEROS, C1 = 0, Hout = Hin, Wout = Win,

@@ -52,6 +52,8 @@ CONV_CASES = [
     (2, 64, 64, 32, 32, 1, 1, 0, "zeros"),
     (2, 256, 128, 4, 4, 1, 1, 0, "zeros"),
     (1, 24, 40, 24, 40, 3, 1, 1, "reflect"),      # ragged: sizes that are not powers of two
+    (2, 4, 64, 16, 64, 3, 1, 1, "zeros"),         # few-input-channel kernel: 2 channel pairs, zero padding
+    (3, 9, 128, 8, 32, 3, 1, 1, "reflect"),       # ... odd channel count, two blocks of 64 output channels, one tile per frame
 ]
 
 
