@@ -107,6 +107,7 @@ __device__ __forceinline__ void group_mean_rstd(const float* __restrict__ part, 
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ rmean, float* __restrict__ rvar,
+                                                         long long* __restrict__ nbt,
                                                          float* __restrict__ gstats, float* __restrict__ row_ab,
                                                          const float* __restrict__ res, float* __restrict__ y,
                                                          const int* __restrict__ valid, c2s_norm_desc d, int segs,
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
             rmean[grp] = (1.f - d.momentum) * rmean[grp] + d.momentum * mu;
             rvar[grp] = (1.f - d.momentum) * rvar[grp] + d.momentum * unb;
         }
+        if (batch && item == 0 && lane == 0 && nbt != nullptr) *nbt += 1;     // num_batches_tracked
     }
     if (first_row && lane == 0) { gstats[grp * 2] = mu; gstats[grp * 2 + 1] = rstd; }   // zeros for a padded GroupNorm frame
     if (!ok) {
@@ -353,7 +355,8 @@ extern "C" size_t c2s_norm_workspace_floats(const c2s_norm_desc* d) {
 }
 
 extern "C" int c2s_norm_fwd(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                            float* running_mean, float* running_var, float* group_stats, float* row_ab,
+                            float* running_mean, float* running_var, long long* num_batches_tracked,
+                            float* group_stats, float* row_ab,
                             const float* residual, float* y, int relu, float* workspace, size_t ws_floats,
                             const int* valid, float pad_value, void* stream) {
     if (int rc = check_desc(d)) return rc;
@@ -371,7 +374,7 @@ extern "C" int c2s_norm_fwd(const c2s_norm_desc* d, const float* x, const float*
         C2S_CHECK_LAUNCH("row_stats");
     }
     hipLaunchKernelGGL(norm_apply_kernel, dim3(cdiv(nitems, 4)), dim3(256), 0, st, x, workspace, gamma, beta, running_mean,
-                       running_var, group_stats, row_ab, residual, y, valid, *d, segs, nitems, relu, pad_value);
+                       running_var, num_batches_tracked, group_stats, row_ab, residual, y, valid, *d, segs, nitems, relu, pad_value);
     C2S_CHECK_LAUNCH("norm_apply");
     return C2S_OK;
 }

@@ -494,13 +494,10 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
     nws = lib().c2s_norm_workspace_floats(C.byref(d))
     ws = ctx.ws.get("norm", nws)
     y = torch.empty_like(x)
-    check(lib().c2s_norm_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
+    nbt = ctx.b.get(prefix + ".num_batches_tracked") if (batch and ctx.training) else None   # int64, bumped by the kernel
+    check(lib().c2s_norm_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv), _ptr(nbt),
                              gstats.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(), int(relu),
                              ws.data_ptr(), ws.numel(), _ptr(valid), float(pad_value), _stream()), "norm_fwd")
-    if batch and ctx.training:
-        nbt = ctx.b.get(prefix + ".num_batches_tracked")
-        if nbt is not None:
-            nbt.add_(1)
     if ctx.tape is None:
         return y
     tape = ctx.tape

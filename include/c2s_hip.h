@@ -205,9 +205,10 @@ typedef struct c2s_norm_desc {
 } c2s_norm_desc;
 
 size_t c2s_norm_workspace_floats(const c2s_norm_desc* d);
-/* running_mean/var: BATCH only (may be NULL for GROUP); updated in place when training */
+/* running_mean/var: BATCH only (may be NULL for GROUP); updated in place when training, and so is the int64 counter
+ * num_batches_tracked (may be NULL) */
 int c2s_norm_fwd(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
-                 float* running_mean, float* running_var, float* group_stats, float* row_ab,
+                 float* running_mean, float* running_var, long long* num_batches_tracked, float* group_stats, float* row_ab,
                  const float* residual, float* y, int relu, float* workspace, size_t ws_floats, const int* valid,
                  float pad_value, void* stream);
 /* gx may alias g.  dbias may be NULL.  g_residual_out: if non-NULL receives a copy of g (residual branch) */

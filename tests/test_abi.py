@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     rc = L.c2s_conv_igemm(ctypes.byref(d), 16, None, 16, None, 16, None, None)
     assert rc == -1 and b"CoutP" in L.c2s_last_error()
     nd = _lib.NormDesc(2, 10, 64, 0, 4, 1, 1e-5, 0.1)                                       # 10 % 4 != 0
-    assert L.c2s_norm_fwd(ctypes.byref(nd), 16, 16, 16, None, None, 16, 16, None, 16, 1, 16, 1 << 20, None, 0.0, None) == -1
+    assert L.c2s_norm_fwd(ctypes.byref(nd), 16, 16, 16, None, None, None, 16, 16, None, 16, 1, 16, 1 << 20, None, 0.0, None) == -1
 
 
 @pytest.mark.parametrize("name", ["utae_eval_pad_wi", "timeunet_eval_pad_wi", "wtae_eval_pad_wi"])

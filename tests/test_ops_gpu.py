@@ -186,6 +186,7 @@ def test_norm_relu_fwd_bwd(kind, shape, use_res, use_valid):
         assert float(out[0].abs().max()) == 0.0
     if kind == "batch":
         assert rel(ctx.b["n.running_mean"], rm2) < 1e-5 and rel(ctx.b["n.running_var"], rv2) < 1e-5
+        assert int(ctx.b["n.num_batches_tracked"]) == 1
     gfull = torch.zeros(shape)
     gfull[keep] = gout
     seed_backward(ctx, out, gfull)
