@@ -18,6 +18,17 @@
 
 namespace {
 
+#ifdef C2S_LT_STAMP
+// diagnostic build only: s_memtime at the phase boundaries of the L-TAE kernels, per workgroup
+__device__ unsigned long long lt_stamps[4096 * 8];
+__device__ unsigned long long lt_stamps_bwd[4096 * 8];
+#define LT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lt_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LT_STAMP_B(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lt_stamps_bwd[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LT_STAMP(k)
+#define LT_STAMP_B(k)
+#endif
+
 constexpr int NH = 16;   // heads == GroupNorm groups (tae.py:428-435)
 constexpr int DV = 16;   // d_model / n_head
 
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
     const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
     const int cpg = C / NH;
     const float* xq = p.x + (size_t)b * T * C * HW + pixq;
+    LT_STAMP_B(0);
 
     if (item < NH) {
         const int g = item;
@@ -280,18 +292,35 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
         *reinterpret_cast<f32x4*>(GAl + i * PT + 4 * q) = p.g_attn != nullptr ? *reinterpret_cast<const f32x4*>(p.g_attn + o) : z4;
     }
     __syncthreads();
+    LT_STAMP_B(1);
 
     if (p.g_emb != nullptr) {
         for (int c0 = 0; c0 < C; c0 += RC) {
-            // A1
-            for (int it = item; it < NH * RC; it += 32) {
-                const int h = it / RC, cc = it % RC;
-                float r = 0.f;
+            // A1 on the 16x16x4 MFMA (rows = pixel, padded 8 -> 16; k = j; columns = 16 channels): wave w owns heads
+            // 4w..4w+3.  (One thread per (pixel, head, channel) with 16 scalar Wc loads each took 57% of this kernel.)
+            {
+                const int wv = tid >> 6, l15 = tid & 15, l4 = (tid & 63) >> 4;
 #pragma unroll
-                for (int j = 0; j < DV; ++j) r = fmaf(GEl[(h * DV + j) * PT + px], p.Wc[(size_t)(h * DV + j) * C + c0 + cc], r);
-                Rl[it * PT + px] = r;
+                for (int hh = 0; hh < 4; ++hh) {
+                    const int h = wv * 4 + hh;
+#pragma unroll
+                    for (int cg = 0; cg < RC / 16; ++cg) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s4 = 0; s4 < DV / 4; ++s4) {
+                            const int j = 4 * s4 + l4;
+                            const float gv = GEl[(h * DV + j) * PT + (l15 & (PT - 1))];
+                            const float a = l15 < PT ? gv : 0.f;
+                            const float bw = p.Wc[(size_t)(h * DV + j) * C + c0 + cg * 16 + l15];
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc, 0, 0, 0);
+                        }
+                        // D[row = 4*l4 + r][col = l15]; rows 0..7 are the pixels of the tile
+                        if (l4 < PT / 4) *reinterpret_cast<f32x4*>(Rl + (h * RC + cg * 16 + l15) * PT + 4 * l4) = acc;
+                    }
+                }
             }
             __syncthreads();
+            if (c0 == 0) LT_STAMP_B(5);
             // A2: slot = (t, half); each half covers RC/2 channels of the chunk
             const int t = slot >> 1, half = slot & 1;
             f32x4 acc[NH];
@@ -309,6 +338,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
                     for (int h = 0; h < NH; ++h) acc[h] += *reinterpret_cast<const f32x4*>(Rl + (h * RC + cc) * PT + 4 * q) * xh;
                 }
             }
+            if (c0 == 0) LT_STAMP_B(6);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 if (t < T && half == hf) {
@@ -320,9 +350,11 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
                 }
                 __syncthreads();
             }
+            if (c0 == 0) LT_STAMP_B(7);
         }
     }
 
+    LT_STAMP_B(2);
     // B: (pixel, head)
     if (item < NH) {
         const int hh = item;
@@ -365,6 +397,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
         }
     }
     __syncthreads();
+    LT_STAMP_B(3);
 
     // C: slots 0..63 produce V = sum_t gs xhat, slots 64..127 produce Z = sum_t attn xhat; channel = slot % 64 (+64)
     {
@@ -393,6 +426,7 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
             }
         }
     }
+    LT_STAMP_B(4);
 }
 
 // ------------------------------------------------------------------------------------------ backward, part 2
@@ -867,16 +901,6 @@ __global__ void ltae_prep_kernel(const float* __restrict__ U, const float* __res
     }
 }
 
-#ifdef C2S_LT_STAMP
-// diagnostic build only: s_memtime at the phase boundaries of the streaming forward, per workgroup
-__device__ unsigned long long lt_stamps[4096 * 8];
-__device__ unsigned long long lt_stamps_bwd[4096 * 8];
-#define LT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lt_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define LT_STAMP_B(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lt_stamps_bwd[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LT_STAMP(k)
-#define LT_STAMP_B(k)
-#endif
 
 template <int CPG>
 __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, const float* __restrict__ Ut,

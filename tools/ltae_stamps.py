@@ -22,7 +22,7 @@ from crop2seg_amd import engine as E  # noqa: E402
 from oracle import seeded  # noqa: E402
 
 dev = torch.device("cuda")
-Bn, T, Cc, h = 8, 61, 64, 128
+Bn, T, Cc, h = (4, 32, 128, 16) if "--utae" in sys.argv else (8, 61, 64, 128)
 ks = [("te.inconv.weight", (256, Cc, 1)), ("te.inconv.bias", (256,)), ("te.attention_head.Q", (16, 1, 4)),
       ("te.attention_head.fc1_k.weight", (64, 256)), ("te.attention_head.fc1_k.bias", (64,)),
       ("te.in_norm.weight", (Cc,)), ("te.in_norm.bias", (Cc,))]
@@ -37,6 +37,19 @@ for _ in range(2):
     ctx.tape.backward()
 torch.cuda.synchronize()
 lib = E.lib()
+if "--utae" in sys.argv:
+    buf = np.zeros(4096 * 8, dtype=np.uint64)
+    lib.c2s_debug_ltae_stamps_bwd.argtypes = [C.c_void_p]
+    assert lib.c2s_debug_ltae_stamps_bwd(buf.ctypes.data) == 0
+    s = buf.reshape(-1, 8).astype(np.int64)
+    s = s[s[:, 0] > 0]
+    print("backward heads kernel (8-pixel tiles, U-TAE bottleneck shape)")
+    for k, n in enumerate(["loads", "A r + dots", "B softmax bwd", "C V/Z"]):
+        v = s[:, k + 1] - s[:, k]
+        print(f"{n:14s} median {np.median(v):9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles")
+    print(f"{'total':14s} median {np.median(s[:, 4] - s[:, 0]):9.0f}")
+    print(f"A, first chunk: A1 r {np.median(s[:, 5] - s[:, 1]):9.0f} | A2 dots {np.median(s[:, 6] - s[:, 5]):9.0f} | add halves {np.median(s[:, 7] - s[:, 6]):9.0f}")
+    sys.exit(0)
 buf = np.zeros(4096 * 8, dtype=np.uint64)
 lib.c2s_debug_ltae_stamps.argtypes = [C.c_void_p]
 assert lib.c2s_debug_ltae_stamps(buf.ctypes.data) == 0
@@ -49,6 +62,7 @@ for k, n in enumerate(names):
 v = s[:, 5] - s[:, 0]
 print(f"{'total':14s} median {np.median(v):9.0f}")
 print(f"P5 round 0: write z + barriers {np.median(s[:, 6] - s[:, 4]):9.0f} | Wc loads + 16 MFMA {np.median(s[:, 7] - s[:, 6]):9.0f} cycles")
+
 
 buf = np.zeros(4096 * 8, dtype=np.uint64)
 lib.c2s_debug_ltae_stamps_bwd.argtypes = [C.c_void_p]
