@@ -183,10 +183,12 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     if (p.emb == nullptr) return;   // W-TAE: attention masks only (tae.py:619)
     __syncthreads();
 
-    // ---- phases 4+5, CH channels at a time
-    float o[DV];
+    // ---- phases 4+5, CH channels at a time.  Phase 5 runs on the 16x16x4 MFMA (rows = pixel, columns = j, k = channel,
+    // then k = time step for the positional term): wave w owns heads 4w..4w+3, one accumulator each.
+    const int l15 = tid & 15, l4 = (tid & 63) >> 4, wv = tid >> 6;
+    f32x4 eacc[4];
 #pragma unroll
-    for (int j = 0; j < DV; ++j) o[j] = 0.f;
+    for (int i = 0; i < 4; ++i) eacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < C; c0 += CH) {
         // 4: z[h] = sum_t attn[h,t] * x[t,c] for channel c = c0 + slot (4 pixels per thread)
         for (int c = c0 + slot; c < c0 + CH; c += 64) {
@@ -207,27 +209,34 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
                     a * z[h] + bb * *reinterpret_cast<const f32x4*>(ASl + h * 16 + 4 * q);
         }
         __syncthreads();
-        // 5: emb slice of (pixel, head)
-        for (int c = 0; c < CH; ++c) {
-            const float zz = Zl[(hh * CH + c) * 16 + px];
+        // 5: emb[px][16h+j] += sum_c z[h][c][px] Wc[16h+j][c]; k-step (m, i) lane-quarter l4 <-> channel 16m + 4*l4 + i
 #pragma unroll
-            for (int j = 0; j < DV; ++j) o[j] = fmaf(p.Wc[(size_t)(hh * DV + j) * C + c0 + c], zz, o[j]);
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int h = wv * 4 + i4;
+            for (int m = 0; m < CH / 16; ++m) {
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(p.Wc + (size_t)(h * DV + l15) * C + c0 + 16 * m + 4 * l4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    eacc[i4] = __builtin_amdgcn_mfma_f32_16x16x4f32(Zl[(h * CH + 16 * m + 4 * l4 + i) * 16 + l15], wq[i], eacc[i4], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
-    {
-        const float asum = ASl[hh * 16 + px];
 #pragma unroll
-        for (int j = 0; j < DV; ++j) o[j] += asum * p.bc[hh * DV + j];
-        for (int t = 0; t < T; ++t) {
-            const float ad = Sl[(t * 16 + hh) * 16 + px];
-#pragma unroll
-            for (int j = 0; j < DV; ++j) o[j] = fmaf(ad, p.pe[(b * T + t) * DV + j], o[j]);
+    for (int i4 = 0; i4 < 4; ++i4) {
+        const int h = wv * 4 + i4;
+        // + sum_t attn[h,t] pe[t][j]  (k = time step, zero beyond T)
+        for (int t0 = 0; t0 < T; t0 += 4) {
+            const int t = t0 + l4;
+            const float av = Sl[((t < T ? t : 0) * 16 + h) * 16 + l15];
+            const float pv = p.pe[(size_t)(b * T + (t < T ? t : 0)) * DV + l15];
+            eacc[i4] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < T ? av : 0.f, pv, eacc[i4], 0, 0, 0);
         }
-        if (act) {
-#pragma unroll
-            for (int j = 0; j < DV; ++j) p.emb[((size_t)b * NH * DV + hh * DV + j) * HW + pix] = o[j];
-        }
+        // D[row = pixel 4*l4 + r][col = j = l15];  + (sum_t attn) * bc[j]
+        const float bcv = p.bc[h * DV + l15];
+        const f32x4 as4 = *reinterpret_cast<const f32x4*>(ASl + h * 16 + 4 * l4);
+        if (pix0 + 4 * l4 < HW)
+            *reinterpret_cast<f32x4*>(p.emb + ((size_t)b * NH * DV + h * DV + l15) * HW + pix0 + 4 * l4) = eacc[i4] + as4 * bcv;
     }
 }
 
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(256) void gwc_mfma_kernel(const float* __restrict__
 //   qWk[h][m] = (1/2) sum_d Q[h][d] Wk[4h+d][m]                    (1/sqrt(d_k) = 1/2)
 //   U[h][c]   = sum_m qWk[h][m] Wc[m][c]
 //   s0[b,t,h] = sum_j (sum_{m = j mod 16} qWk[h][m]) pe[b,t,j] + sum_m qWk[h][m] bc[m] + (1/2) sum_d Q[h][d] bk[4h+d]
-// One workgroup each for the forward and its adjoint (a few MFLOP); fixed summation orders.
+// One workgroup per head for the forward, one workgroup per adjoint stage (a few MFLOP); fixed summation orders.
 // Replaces positional_encoding.py:16-33 and the key/query algebra of tae.py:790-830 on the parameter side.
 constexpr int DM = NH * DV;      // 256
 constexpr int DK = 4;
@@ -651,52 +660,61 @@ __global__ void positional_table_kernel(const long long* __restrict__ dates, flo
     pe[e] = (j & 1) ? cosf(a) : sinf(a);
 }
 
+// one workgroup per head (a single workgroup spent 47 us in 512 dependent loads per thread)
 __global__ __launch_bounds__(1024) void ltae_fold_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
                                                              const float* __restrict__ bk, const float* __restrict__ Wc,
                                                              const float* __restrict__ bc, const float* __restrict__ pe,
                                                              float* __restrict__ U, float* __restrict__ s0,
                                                              float* __restrict__ qwk, int BT, int C) {
-    __shared__ float q[NH * DM];
-    __shared__ float qs[NH * DV];
-    __shared__ float k0[NH];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NH * DM; e += 1024) {
-        const int h = e / DM, m = e % DM;
+    __shared__ float q[DM];
+    __shared__ float qs[DV];
+    __shared__ float red[1024];
+    __shared__ float k0;
+    const int tid = threadIdx.x, h = blockIdx.x;
+    if (tid < DM) {
         float v = 0.f;
 #pragma unroll
-        for (int d = 0; d < DK; ++d) v = fmaf(Q[h * DK + d], Wk[(size_t)(h * DK + d) * DM + m], v);
+        for (int d = 0; d < DK; ++d) v = fmaf(Q[h * DK + d], Wk[(size_t)(h * DK + d) * DM + tid], v);
         v *= 0.5f;
-        q[e] = v;
-        qwk[e] = v;
+        q[tid] = v;
+        qwk[h * DM + tid] = v;
     }
     __syncthreads();
-    if (tid < NH * DV) {
-        const int h = tid / DV, j = tid % DV;
+    if (tid < DV) {
         float v = 0.f;
-        for (int i = 0; i < DM / DV; ++i) v += q[h * DM + i * DV + j];
+        for (int i = 0; i < DM / DV; ++i) v += q[i * DV + tid];
         qs[tid] = v;
     }
-    if (tid >= 512 && tid < 512 + NH) {
-        const int h = tid - 512;
+    if (tid == 64) {
         float v = 0.f;
-        for (int m = 0; m < DM; ++m) v = fmaf(q[h * DM + m], bc[m], v);
+        for (int m = 0; m < DM; ++m) v = fmaf(q[m], bc[m], v);
         float qb = 0.f;
         for (int d = 0; d < DK; ++d) qb = fmaf(Q[h * DK + d], bk[h * DK + d], qb);
-        k0[h] = v + 0.5f * qb;
+        k0 = v + 0.5f * qb;
+    }
+    // U[h][c] = sum_m q[m] Wc[m][c]: thread = (c, part); the parts (contiguous m ranges) are summed in order through LDS
+    const int parts = 1024 / C, mlen = (DM + parts - 1) / parts;
+    {
+        const int c = tid % C, part = tid / C;
+        float v = 0.f;
+        if (part < parts) {
+            const int m0 = part * mlen, m1 = min(DM, m0 + mlen);
+#pragma unroll 8
+            for (int m = m0; m < m1; ++m) v = fmaf(q[m], Wc[(size_t)m * C + c], v);
+        }
+        red[tid] = v;
     }
     __syncthreads();
-    for (int e = tid; e < NH * C; e += 1024) {
-        const int h = e / C, c = e % C;
+    if (tid < C) {
         float v = 0.f;
-        for (int m = 0; m < DM; ++m) v = fmaf(q[h * DM + m], Wc[(size_t)m * C + c], v);
-        U[e] = v;
+        for (int part = 0; part < parts; ++part) v += red[part * C + tid];
+        U[h * C + tid] = v;
     }
-    for (int e = tid; e < BT * NH; e += 1024) {
-        const int bt = e / NH, h = e % NH;
-        float v = k0[h];
+    for (int bt = tid; bt < BT; bt += 1024) {
+        float v = k0;
 #pragma unroll
-        for (int j = 0; j < DV; ++j) v = fmaf(qs[h * DV + j], pe[(size_t)bt * DV + j], v);
-        s0[e] = v;
+        for (int j = 0; j < DV; ++j) v = fmaf(qs[j], pe[(size_t)bt * DV + j], v);
+        s0[bt * NH + h] = v;
     }
 }
 
@@ -1823,7 +1841,8 @@ extern "C" int c2s_positional_table(const long long* dates, float* pe, long n, f
 extern "C" int c2s_ltae_fold_fwd(const float* Q, const float* Wk, const float* bk, const float* Wc, const float* bc,
                                  const float* pe, float* U, float* s0, float* qwk, int BT, int C, void* stream) {
     C2S_REQUIRE(Q && Wk && bk && Wc && bc && pe && U && s0 && qwk && BT > 0 && C > 0, "ltae_fold_fwd: bad args");
-    hipLaunchKernelGGL(ltae_fold_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, Q, Wk, bk, Wc, bc, pe, U, s0, qwk, BT, C);
+    C2S_REQUIRE(C <= 1024, "ltae_fold_fwd: C > 1024");
+    hipLaunchKernelGGL(ltae_fold_fwd_kernel, dim3(NH), dim3(1024), 0, (hipStream_t)stream, Q, Wk, bk, Wc, bc, pe, U, s0, qwk, BT, C);
     C2S_CHECK_LAUNCH("ltae_fold_fwd");
     return C2S_OK;
 }
