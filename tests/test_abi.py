@@ -39,6 +39,23 @@ def test_argument_validation_without_gpu():
     assert L.c2s_norm_fwd(ctypes.byref(nd), 16, 16, 16, None, None, None, 16, 16, None, 16, 1, 16, 1 << 20, None, 0.0, None) == -1
 
 
+def test_smallcin_dispatch_predicate_without_gpu():
+    """The first-layer kernel's host-side predicate: 3x3/s1/pad1, one source of <= 10 channels, Cout % 64 == 0,
+    H % 8 == 0, W % 32 == 0, plain output placement."""
+    from crop2seg_amd import _lib
+    L = _lib.lib()
+
+    def desc(c0=10, cout=64, h=128, w=128, k=3, s=1, pad=1, c1=0, acc=0):
+        return _lib.ConvDesc(4, c0, c1, h, w, cout, cout, h, w, h, w, k, k, s, pad, pad, _lib.PAD_REFLECT, 1, 1, 0, 0, acc)
+
+    assert L.c2s_conv3x3_smallcin_supported(ctypes.byref(desc())) == 1
+    assert L.c2s_conv3x3_smallcin_supported(ctypes.byref(desc(c0=4, h=8, w=32))) == 1
+    for bad in (desc(c0=11), desc(cout=32), desc(h=12), desc(w=48), desc(c1=2), desc(acc=1), desc(k=1, pad=0)):
+        assert L.c2s_conv3x3_smallcin_supported(ctypes.byref(bad)) == 0
+    rc = L.c2s_conv3x3_smallcin(ctypes.byref(desc(c0=11)), 16, 16, None, 16, None, None)
+    assert rc == -1 and b"smallcin" in L.c2s_last_error()
+
+
 @pytest.mark.parametrize("name", ["utae_eval_pad_wi", "timeunet_eval_pad_wi", "wtae_eval_pad_wi"])
 def test_state_dict_layout_matches_reference(goldens, name):
     import crop2seg_amd as C2S
