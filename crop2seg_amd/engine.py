@@ -26,6 +26,20 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+import os as _os
+
+_SIDE = None
+SIDE_WGRAD = _os.environ.get("C2S_WGRAD_STREAM", "1") != "0"
+SIDE_BATCH = int(_os.environ.get("C2S_WGRAD_BATCH", "8"))
+
+
+def _side_stream():
+    global _SIDE
+    if _SIDE is None:
+        _SIDE = torch.cuda.Stream()
+    return _SIDE
+
+
 def _tap_array(offs: Sequence[int]):
     return (C.c_int * len(offs))(*offs)
 
@@ -76,6 +90,20 @@ class Tape:
         self.ops: List[Callable[[], None]] = []
         self.grads: Dict[int, Tensor] = {}
         self.keep: List[Tensor] = []      # keeps forward tensors alive (ids stay unique)
+        self.side_keep: List[Tensor] = []  # operands of kernels running on the side stream (alive until the join)
+        self.side_used = False
+        self.side_pending: List[Callable[[], None]] = []   # weight-gradient launches waiting for the next fork
+
+    def fork(self) -> "torch.cuda.Stream":
+        """Side HIP stream ordered after everything issued so far on the current stream.  Weight gradients feed nothing
+        until the optimizer, so they run there, next to the data-gradient chain, and fill the CUs that the small
+        kernels of the chain (16x16 maps, decoder at N = B, L-TAE) leave idle; `backward()` joins the stream."""
+        side = _side_stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        self.side_used = True
+        return side
 
     def record(self, fn: Callable[[], None]) -> None:
         self.ops.append(fn)
@@ -98,9 +126,32 @@ class Tape:
         else:
             check(lib().c2s_add_inplace(cur.data_ptr(), g.data_ptr(), g.numel(), _stream()), "add_inplace")
 
+    def defer(self, fn: Callable[[], None], keep: Sequence[Tensor]) -> None:
+        """Queue a launch for the side stream; a fork is issued every SIDE_BATCH launches (each fork/join is an edge of
+        the captured hipGraph, and edges are not free)."""
+        self.side_pending.append(fn)
+        self.side_keep.extend(keep)
+        if len(self.side_pending) >= SIDE_BATCH:
+            self.flush_side()
+
+    def flush_side(self) -> None:
+        if not self.side_pending:
+            return
+        with torch.cuda.stream(self.fork()):
+            for fn in self.side_pending:
+                fn()
+        self.side_pending.clear()
+
     def backward(self) -> None:
         for fn in reversed(self.ops):
             fn()
+        self.flush_side()
+        if self.side_used:
+            ev = torch.cuda.Event()
+            ev.record(_side_stream())
+            torch.cuda.current_stream().wait_event(ev)
+            self.side_used = False
+        self.side_keep.clear()
         self.ops.clear()
         self.keep.clear()
 
@@ -300,6 +351,17 @@ def _wgrad_slices(ctx: Ctx, N: int, Hout: int, Wout: int, S: int, cin: int, cout
 def _wgrad(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int, Wout: int, K: int, S: int, pad: int,
            pad_mode: int, dst: Tensor, so: int, sc: int, taps: Sequence[int], accumulate: int,
            valid: Optional[Tensor]) -> None:
+    """Weight gradient of a convolution into `dst` (split-K slabs + fixed-order slice sum), on the side stream."""
+    if SIDE_WGRAD and ctx.tape is not None and not torch.cuda.is_current_stream_capturing():   # a captured graph gained nothing from the fork
+        ctx.tape.defer(lambda: _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps,
+                                             accumulate, valid), [gout, *srcs])
+    else:
+        _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps, accumulate, valid)
+
+
+def _wgrad_launch(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int, Wout: int, K: int, S: int, pad: int,
+                  pad_mode: int, dst: Tensor, so: int, sc: int, taps: Sequence[int], accumulate: int,
+                  valid: Optional[Tensor]) -> None:
     s0 = srcs[0]
     s1 = srcs[1] if len(srcs) > 1 else None
     N, C0, Hin, Win = s0.shape
