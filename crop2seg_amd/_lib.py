@@ -80,6 +80,7 @@ SIGNATURES = {
     "c2s_norm_workspace_floats": (SZ, [C.POINTER(NormDesc)]),
     "c2s_norm_fwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, P, P, P, P, P, I, P, SZ, P, F, P]),
     "c2s_norm_bwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, I, P, P, P, P, P, SZ, P, P]),
+    "c2s_norm_bwd_params": (I, [C.POINTER(NormDesc), P, P, P, P, P, P]),
     "c2s_frame_flags": (I, [P, P, I, L, F, P]),
     "c2s_ltae_attn_fwd": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P]),
     "c2s_positional_table": (I, [P, P, L, C.c_float, P]),

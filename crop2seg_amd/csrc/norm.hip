@@ -404,3 +404,13 @@ extern "C" int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float*
     }
     return C2S_OK;
 }
+
+extern "C" int c2s_norm_bwd_params(const c2s_norm_desc* d, const float* workspace, float* dgamma, float* dbeta,
+                                   float* dbias, const int* valid, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    C2S_REQUIRE(workspace && (dgamma || dbeta || dbias), "norm_bwd_params: null pointer");
+    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3(d->C), dim3(64), 0, (hipStream_t)stream, workspace, dgamma, dbeta, dbias,
+                       valid, d->N, d->C, n_segs(d->HW));
+    C2S_CHECK_LAUNCH("norm_bwd_params");
+    return C2S_OK;
+}

@@ -520,10 +520,17 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
         gw, acc = ctx.grad_sink(wname)
         part = ctx.ws.get("dw_partial", N * Cc * K * K)
         tgt = gw if not acc else torch.empty_like(gw)
-        check(lib().c2s_dwconv_wgrad(x.data_ptr(), g.data_ptr(), part.data_ptr(), tgt.data_ptr(), _ptr(valid), N, Cc, Hin,
-                                     Win, K, S, pad, pad_mode, _stream()), "dwconv_wgrad")
-        if acc:
-            check(lib().c2s_add_inplace(gw.data_ptr(), tgt.data_ptr(), tgt.numel(), _stream()), "add_inplace")
+
+        def wgrad():
+            check(lib().c2s_dwconv_wgrad(x.data_ptr(), g.data_ptr(), part.data_ptr(), tgt.data_ptr(), _ptr(valid), N, Cc, Hin,
+                                         Win, K, S, pad, pad_mode, _stream()), "dwconv_wgrad")
+            if acc:
+                check(lib().c2s_add_inplace(gw.data_ptr(), tgt.data_ptr(), tgt.numel(), _stream()), "add_inplace")
+
+        if SIDE_WGRAD and not torch.cuda.is_current_stream_capturing():
+            tape.defer(wgrad, [x, g, tgt])              # side stream, next to the data-gradient chain
+        else:
+            wgrad()
         existing = tape.grad_of(x)                      # e.g. the residual branch of the block: accumulate in the kernel
         gin = existing if existing is not None else torch.empty_like(x)
         check(lib().c2s_dwconv_dgrad(g.data_ptr(), W.data_ptr(), gin.data_ptr(), _ptr(valid), N, Cc, Hin, Win, K, S, pad,
@@ -577,10 +584,20 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
         dgamma, _ = ctx.grad_sink(prefix + ".weight")
         dbeta, _ = ctx.grad_sink(prefix + ".bias")
         dbias = ctx.grad_sink(conv_bias)[0] if conv_bias else None
-        ws2 = ctx.ws.get("norm", nws)
-        check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
-                                 row_ab.data_ptr(), int(relu), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                 _ptr(dbias), ws2.data_ptr(), ws2.numel(), _ptr(valid), _stream()), "norm_bwd")
+        if SIDE_WGRAD and not torch.cuda.is_current_stream_capturing():
+            # the parameter gradients (one wave per channel: a launch that leaves the GPU idle) go to the side stream; their
+            # partial sums live in a buffer of their own until the join
+            ws2 = torch.empty(nws, device=x.device, dtype=torch.float32)
+            check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
+                                     row_ab.data_ptr(), int(relu), gx.data_ptr(), None, None, None, ws2.data_ptr(),
+                                     ws2.numel(), _ptr(valid), _stream()), "norm_bwd")
+            tape.defer(lambda: check(lib().c2s_norm_bwd_params(C.byref(d), ws2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                               _ptr(dbias), _ptr(valid), _stream()), "norm_bwd_params"), [ws2])
+        else:
+            ws2 = ctx.ws.get("norm", nws)
+            check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
+                                     row_ab.data_ptr(), int(relu), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                     _ptr(dbias), ws2.data_ptr(), ws2.numel(), _ptr(valid), _stream()), "norm_bwd")
         tape.add_grad(x, gx)
 
     tape.record(bwd)

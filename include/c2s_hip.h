@@ -211,10 +211,14 @@ int c2s_norm_fwd(const c2s_norm_desc* d, const float* x, const float* gamma, con
                  float* running_mean, float* running_var, long long* num_batches_tracked, float* group_stats, float* row_ab,
                  const float* residual, float* y, int relu, float* workspace, size_t ws_floats, const int* valid,
                  float pad_value, void* stream);
-/* gx may alias g.  dbias may be NULL.  g_residual_out: if non-NULL receives a copy of g (residual branch) */
+/* gx may alias g.  dgamma, dbeta, dbias may be NULL (all NULL: the parameter-gradient launch is skipped).  g_residual_out: if non-NULL receives a copy of g (residual branch) */
 int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float* g, const float* gamma,
                  const float* group_stats, const float* row_ab, int relu, float* gx, float* dgamma,
                  float* dbeta, float* dbias, float* workspace, size_t ws_floats, const int* valid, void* stream);
+/* The parameter gradients alone, from the workspace a c2s_norm_bwd call (with dgamma = dbeta = dbias = NULL) left behind:
+ * lets the caller run this small launch on another stream, next to the data-gradient chain. */
+int c2s_norm_bwd_params(const c2s_norm_desc* d, const float* workspace, float* dgamma, float* dbeta, float* dbias,
+                        const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Frame flags: valid[n] = any(x[n] != pad_value)   (utae.py:201-203, temp_shared_block.py:31)
