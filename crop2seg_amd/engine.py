@@ -31,6 +31,7 @@ import os as _os
 _SIDE = None
 SIDE_WGRAD = _os.environ.get("C2S_WGRAD_STREAM", "1") != "0"
 SIDE_BATCH = int(_os.environ.get("C2S_WGRAD_BATCH", "8"))
+SIDE_FLUSH_POSITIONS = int(_os.environ.get("C2S_WGRAD_FLUSH_POSITIONS", str(1 << 19)))
 
 
 def _side_stream():
@@ -355,6 +356,9 @@ def _wgrad(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int,
     if SIDE_WGRAD and ctx.tape is not None and not torch.cuda.is_current_stream_capturing():   # a captured graph gained nothing from the fork
         ctx.tape.defer(lambda: _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps,
                                              accumulate, valid), [gout, *srcs])
+        if srcs[0].shape[0] * Hout * Wout >= SIDE_FLUSH_POSITIONS:
+            ctx.tape.flush_side()       # the full-resolution layers come last in the backward pass: start them now, while
+                                        # the rest of the chain can still overlap them, instead of after it
     else:
         _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps, accumulate, valid)
 
