@@ -112,15 +112,16 @@ class Golden:
         # exists, oracle/make_golden.py), and the reference's own fp32 gradients differ from themselves by 1.5-3.6e-2
         # between thread counts there -> relative floor 1e-2 instead of 1e-3
         # Kink flips make that noise heavy-tailed (one flipped unit moves a whole BatchNorm channel's gradient), so for
-        # this flavour a single tensor may reach 10x the reference's deviation; callers additionally require that at
-        # most 10 % of the tensors exceed the 5x bound (self.soft_violations).  A wrong kernel is off by O(1).
+        # this flavour a single tensor may reach 10x the reference's deviation or 4e-2 relative (the reference's own
+        # thread-count-to-thread-count deviation reaches 3.6e-2); callers additionally require that at most 10 % of the
+        # tensors exceed the 5x / 1e-2 bound (self.soft_violations).  A wrong kernel is off by O(1).
         wi = self.meta["flavour"] == "wi"
         floor, factor = (1e-2, 5) if wi else (1e-3, 3)
         bound = max(factor * err_ref, floor * scale) + 1e-6 * gmax
         if wi:
             if err > bound:
                 self.soft_violations = getattr(self, "soft_violations", []) + [(name, err / scale, err_ref / scale)]
-            bound = max(2 * factor * err_ref, floor * scale) + 1e-6 * gmax
+            bound = max(2 * factor * err_ref, 4 * floor * scale) + 1e-6 * gmax
         assert err <= bound, (name, err / scale, err_ref / scale)
         return err / scale
 
