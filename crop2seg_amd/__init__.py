@@ -3,7 +3,13 @@
 U-TAE / TimeUNet_v1 / W-TAE forward + backward as hand-written HIP kernels behind a C ABI
 (include/c2s_hip.h, libc2s_hip.so), with the reference's model-constructor / forward() / state_dict surface.
 """
-from .backbones.modules import UTAE, WTAE, TimeUNet_v1  # noqa: F401
-from .learning.utils import get_model, weight_init  # noqa: F401
+import os as _os
+
+# Two HIP streams per step + the streams RCCL creates need more than the runtime's default 4 hardware queues, or the side
+# stream shares a queue with the main one (DESIGN.md section 5).  Only effective if HIP is not initialised yet.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .backbones.modules import UTAE, WTAE, TimeUNet_v1  # noqa: E402,F401
+from .learning.utils import get_model, weight_init  # noqa: E402,F401
 
 __all__ = ["UTAE", "WTAE", "TimeUNet_v1", "get_model", "weight_init"]
