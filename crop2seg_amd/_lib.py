@@ -9,7 +9,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libc2s_hip.so")
+LIB_PATH = os.environ.get("C2S_LIB", os.path.join(HERE, "libc2s_hip.so"))   # C2S_LIB: an alternative build (A/B runs)
 
 c_float_p = C.c_void_p   # device pointers are passed as integers (tensor.data_ptr())
 c_int_p = C.c_void_p
