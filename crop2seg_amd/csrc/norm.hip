@@ -165,7 +165,29 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     }
     const float a = gamma[c] * rstd, b = beta[c];
     if (seg == 0 && lane == 0) { row_ab[row * 3] = a; row_ab[row * 3 + 1] = b; row_ab[row * 3 + 2] = mu; }
-    if ((len & 3) == 0) {
+    if (len == SEG) {
+        // full segment: every load of the lane is requested before the first use (the rolled loop below keeps one round per
+        // wave in flight)
+        f32x4 v[SEG / 256], r[SEG / 256];
+#pragma unroll
+        for (int k = 0; k < SEG / 256; ++k) v[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
+        if (res != nullptr) {
+#pragma unroll
+            for (int k = 0; k < SEG / 256; ++k) r[k] = *reinterpret_cast<const f32x4*>(res + base + lane * 4 + 256 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < SEG / 256; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[k][e] - mu) * a + b;
+                if (relu) t = fmaxf(t, 0.f);
+                if (res != nullptr) t += r[k][e];
+                o[e] = t;
+            }
+            *reinterpret_cast<f32x4*>(y + base + lane * 4 + 256 * k) = o;
+        }
+    } else if ((len & 3) == 0) {
         for (int i = lane * 4; i < len; i += 256) {
             f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
             v.x = (v.x - mu) * a + b; v.y = (v.y - mu) * a + b; v.z = (v.z - mu) * a + b; v.w = (v.w - mu) * a + b;
@@ -212,7 +234,23 @@ __global__ __launch_bounds__(256) void norm_bwd_sums_kernel(const float* __restr
     const float mean = gstats[grp * 2], rstd = gstats[grp * 2 + 1];
     const float a = row_ab[row * 3], b = row_ab[row * 3 + 1];
     float s1 = 0.f, s2 = 0.f;
-    if ((len & 3) == 0) {
+    if (len == SEG) {
+        f32x4 xa[SEG / 256], ga[SEG / 256];                       // all 16 loads of the lane in flight at once
+#pragma unroll
+        for (int k = 0; k < SEG / 256; ++k) {
+            xa[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
+            ga[k] = *reinterpret_cast<const f32x4*>(g + base + lane * 4 + 256 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < SEG / 256; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xx = xa[k][e];
+                const float gg = (!relu || (xx - mean) * a + b > 0.f) ? ga[k][e] : 0.f;
+                s1 += gg;
+                s2 += gg * ((xx - mean) * rstd);
+            }
+    } else if ((len & 3) == 0) {
         for (int i = lane * 4; i < len; i += 256) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
             const f32x4 gv = *reinterpret_cast<const f32x4*>(g + base + i);
@@ -326,7 +364,26 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     }
     const float a = row_ab[row * 3], b = row_ab[row * 3 + 1], mu = row_ab[row * 3 + 2];
     float sdx = 0.f;
-    if ((len & 3) == 0) {
+    if (len == SEG) {
+        f32x4 xa[SEG / 256], ga[SEG / 256];                       // all 16 loads of the lane in flight at once
+#pragma unroll
+        for (int k = 0; k < SEG / 256; ++k) {
+            xa[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
+            ga[k] = *reinterpret_cast<const f32x4*>(g + base + lane * 4 + 256 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < SEG / 256; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xc = xa[k][e] - mu;
+                const float gg = (!relu || xc * a + b > 0.f) ? ga[k][e] : 0.f;
+                o[e] = k1 * gg + k2 * xc + k3;
+                sdx += o[e];
+            }
+            *reinterpret_cast<f32x4*>(gx + base + lane * 4 + 256 * k) = o;
+        }
+    } else if ((len & 3) == 0) {
         for (int i = lane * 4; i < len; i += 256) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
             const f32x4 gv = *reinterpret_cast<const f32x4*>(g + base + i);
