@@ -102,6 +102,11 @@ def main():
                          "default because the weight gradients then overlap the data-gradient chain on a side stream")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     args = ap.parse_args()
+    # stdout carries exactly one line (the JSON): anything libraries write to file descriptor 1 while the bench runs --
+    # RCCL prints a five-line version banner there when its communicator is created -- goes to stderr instead
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -231,6 +236,8 @@ def main():
                 pass
             threads = min(threads, args.cpu_threads)        # a 1-GPU box owns a 16-core share of the host
             out["cpu_baseline"] = cpu_baseline(T, H, H, threads)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if distributed:
         import torch.distributed as dist
