@@ -7,6 +7,7 @@ This module has no HIP dependency so that the N > 1 logic is testable without a 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -28,6 +29,6 @@ class FlatDataParallel:
     def reduce_gradients(self, flat_grad: torch.Tensor) -> float:
         """Sum the flat gradient buffer over ranks in place; returns the scale (1/world) the optimiser must apply
         (folded into the Adam kernel instead of a separate divide pass)."""
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("C2S_BENCH_FORCE_DIST") == "1":     # the override rehearses the launch on one GPU
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
