@@ -376,7 +376,6 @@ __global__ __launch_bounds__(256) void ltae_bwd_heads_kernel(LtaeParams p) {
         }
         float dsum = 0.f, asum = 0.f;
         for (int t = 0; t < T; ++t) {
-            const size_t o = ((size_t)(hh * p.B + b) * T + t) * HW + pix;
             float gap = Dl[(t * NH + hh) * PT + px] + gebc + GAl[(t * NH + hh) * PT + px];
 #pragma unroll
             for (int j = 0; j < DV; ++j) gap = fmaf(ge[j], p.pe[(b * T + t) * DV + j], gap);
