@@ -61,7 +61,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr int NS = NT * (CK / 2);            // MFMA k-steps per chunk
     extern __shared__ float lds[];
 
-    const int n = blockIdx.z;
+    // XCD-aware placement (workgroups go to the 8 XCDs round-robin in linear order): each XCD takes a contiguous eighth of the
+    // (frame, tile) range, so tiles that share halo rows are processed behind the same L2
+    int bxi = blockIdx.x, n = blockIdx.z;
+    {
+        const unsigned tot = gridDim.x * gridDim.z;
+        if (gridDim.y == 1 && (tot & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+            const unsigned l2_ = (lin & 7) * (tot >> 3) + (lin >> 3);
+            n = (int)(l2_ / gridDim.x);
+            bxi = (int)(l2_ - (unsigned)n * gridDim.x);
+        }
+    }
     if (p.valid != nullptr && p.valid[n] == 0) return;
 
     const int FC = 1 << p.log2fc, FR = 32 >> p.log2fc;
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     float* Wl = lds + xsz;
     const int BUF = xsz + NT * CK * COT;
 
-    const int tyi = blockIdx.x / p.tiles_x, txi = blockIdx.x % p.tiles_x;
+    const int tyi = bxi / p.tiles_x, txi = bxi % p.tiles_x;
     const int oy0 = tyi * tile_h, ox0 = txi * tile_w;
     const int co0 = blockIdx.y * COT;
     const int tid = threadIdx.x;

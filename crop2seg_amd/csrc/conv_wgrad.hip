@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(WgradParams p) 
         return tile;
     };
 
-    int tile = next_tile(slice);
+    // XCD-aware start (see conv_winograd.hip): each XCD walks a contiguous eighth of the tiles in flight, so vertically
+    // adjacent tiles (shared halo rows) meet in one L2; the slab index stays the workgroup index
+    int tile = next_tile((p.nslices & 7) == 0 ? (slice & 7) * (p.nslices >> 3) + (slice >> 3) : slice);
     if (tile < p.ntiles) prefetch(tile);
     while (tile < p.ntiles) {
         commit();
@@ -585,7 +587,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
         }
     };
 
-    int tile = next_tile(slice);
+    // XCD-aware start (see conv_winograd.hip): each XCD walks a contiguous eighth of the tiles in flight, so vertically
+    // adjacent tiles (shared halo rows) meet in one L2; the slab index stays the workgroup index
+    int tile = next_tile((p.nslices & 7) == 0 ? (slice & 7) * (p.nslices >> 3) + (slice >> 3) : slice);
     if (tile < p.ntiles) prefetch(tile);
     while (tile < p.ntiles) {
         commit();

@@ -231,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void conv_winograd_kernel(WinoParams p) {
         V[2] = t2 - t1;
     };
 
-    int t = next_valid(blockIdx.x);
+    // XCD-aware start: workgroups are dealt to the 8 XCDs round-robin, so workgroup b and b+1 have different L2s.  Give each
+    // XCD a contiguous eighth of the 2*CUs tiles in flight (half a frame at 128x128): vertically adjacent tiles, which share
+    // two of their six input rows, then meet in the same L2 instead of fetching the halo from HBM twice.
+    const int wg0 = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    int t = next_valid(wg0);
     if (t >= ntotal) return;
     WN_STAMP_DECL
     begin_tile(t);
