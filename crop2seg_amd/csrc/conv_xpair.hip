@@ -9,7 +9,7 @@
 // half-used 32-byte sectors and 4 passes over the output; this kernel is 2 launches with full-line stores.)
 // GEMM mapping as in conv_igemm.hip (A = weights, rows = output channel; B = gathered input, columns =
 // position); workgroup = 4 waves, wave w owns position fragment w (32 sub-grid positions) x 32*MF channels x 2
-// parities = 2*MF accumulators; K loop over input channels in LDS-double-buffered chunks of 8.
+// parities = 2*MF accumulators; K loop over input channels in LDS-double-buffered chunks of 4 (21 KB of LDS per workgroup: more resident workgroups hide more than the extra barriers cost; 8 and 2 were both slower).
 //
 // Reference call sites replaced: nn.ConvTranspose2d(k=4,s=2,p=1) forward (src/backbones/conv.py:384-390) and the
 // convolution_backward-input of the 4x4 stride-2 down convolutions (conv.py:263-271), including the adjoint of
@@ -31,7 +31,7 @@ struct XpParams {
                            // px=0: position Wout-1 / tap tx=0 also reads column j ; px=1: position 0 / tap tx=1 too
 };
 
-constexpr int XP_CK = 8;
+constexpr int XP_CK = 4;
 constexpr int xp_plane(int l2) { return (4 * (32 >> l2) + 1) * ((1 << l2) + 2); }
 constexpr int xp_cmax(int a, int b) { return a > b ? a : b; }
 constexpr int XP_MAXPLANE = xp_cmax(xp_cmax(xp_plane(2), xp_plane(3)), xp_cmax(xp_plane(4), xp_plane(5)));
