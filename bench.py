@@ -35,35 +35,28 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X dense fp32 MFMA/vector peak (MI355X_MICROARCH.md, chip-level parameters)
-# HBM bytes of ONE launch of the dominant kernel (64->64 3x3 @128x128, N=128): rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate passes (profiles/r01_pmc_winograd_64x64_128px.csv): 995,960 KiB + 524,288 KiB.
-# FETCH_SIZE is quoted uncorrected: the x2 correction of the micro-architecture guide is calibrated for 16-B/lane
-# streaming reads, this kernel gathers 4 B/lane.  Algorithmic bytes: 537 MB in + 537 MB out + 0.15 MB weights
-# (the fetch excess is the halo of the 4x32-pixel tiles: 6x34 / 4x32 = 1.6x).
-DOMINANT_KERNEL_TRAFFIC_BYTES = (995960.4 + 524288.0) * 1024
-DOMINANT_KERNEL_TRAFFIC_BYTES_DIRECT = (822876.8 + 524288.0) * 1024    # C2S_WINOGRAD=0 / bf16x3: conv_igemm_kernel
+# HBM bytes of ONE launch of the dominant kernel come from a committed rocprofv3 --pmc run (FETCH_SIZE and WRITE_SIZE in
+# separate passes, tools/pmc_traffic.py) -- never from a constant in this file.  The file names the commit / date /
+# command it was measured with; without it `traffic` is null.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+
+# algorithmic FLOPs per patch, forward: (a*T + b) * H*W; a train step is 3x (forward, data and weight gradients)
+STEP_FLOPS = {"utae": (182962, 161216), "timeunet": (151424, 288960), "wtae": (96936, 256192)}
 
 
-def synthetic_batch(B, T, H, W, seed, device, n_classes=15):
-    """x ~ N(0,1) f32 [B,T,10,H,W]; dates = 5*t; y ~ U{0..14}; generator seed = 1 + rank."""
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, T, 10, H, W, generator=g)
-    dates = (5 * torch.arange(T))[None, :].repeat(B, 1).to(torch.int64)
-    y = torch.randint(0, n_classes, (B, H, W), generator=g)
-    return x.to(device), dates.to(device), y.to(device)
+def dominant_traffic(kernel_key, N, H):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        e = t.get(kernel_key)
+        if e and e.get("N") == N and e.get("H") == H:
+            return e["bytes_per_launch"], f"profiles/{os.path.basename(TRAFFIC_FILE)}: {e.get('source', '')}"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
-def cpu_baseline(T, H, W, threads):
-    """One train step of the CPU oracle (fwd + CE + bwd + Adam) on a bounded sample of the same workload."""
-    from oracle import crop2seg_oracle as O
-    import crop2seg_amd as C2S
-    torch.set_num_threads(threads)
-    torch.manual_seed(1)
-    net = C2S.UTAE(input_dim=10, out_conv=[32, 15])
-    net.apply(C2S.weight_init)
-    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    cfg = O.BackboneConfig()
-    B = 2
+def _cpu_steps(O, sd, cfg, B, T, H, W, n_warm, n_timed):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, T, 10, H, W, generator=g)
     dates = (5 * torch.arange(T))[None, :].repeat(B, 1).to(torch.int64)
@@ -72,16 +65,40 @@ def cpu_baseline(T, H, W, threads):
     ak = (torch.rand(16, P, T, generator=g) >= 0.1).float()
     mk = (torch.rand(P, 128, generator=g) >= 0.2).float()
     names = O.parameter_names(sd)
+    params = {n: sd[n].clone() for n in names}
     m = {n: torch.zeros_like(sd[n]) for n in names}
     v = {n: torch.zeros_like(sd[n]) for n in names}
-    t0 = time.perf_counter()
-    _, loss, grads, bn = O.loss_and_grads(sd, x, dates, y, cfg, True, attn_keep=ak, mlp_keep=mk)
-    params = {n: sd[n] for n in names}
-    O.adam_step(params, grads, m, v, 1)
-    dt = time.perf_counter() - t0
+    times = []
+    for it in range(n_warm + n_timed):
+        t0 = time.perf_counter()
+        cur = dict(sd)
+        cur.update(params)
+        _, loss, grads, bn = O.loss_and_grads(cur, x, dates, y, cfg, True, attn_keep=ak, mlp_keep=mk)
+        O.adam_step(params, grads, m, v, it + 1)
+        if it >= n_warm:
+            times.append(time.perf_counter() - t0)
+    return sum(times) / len(times)
+
+
+def cpu_baseline(B, T, H, W, threads):
+    """Train steps of the CPU oracle (fwd + CE + bwd + Adam, train mode) on this host's cores: the workload of the
+    bench line (1 warm-up + 3 timed steps) and BASELINE.json configs[0] (U-TAE B=2, T=16)."""
+    from oracle import crop2seg_oracle as O
+    import crop2seg_amd as C2S
+    torch.set_num_threads(threads)
+    torch.manual_seed(1)
+    net = C2S.UTAE(input_dim=10, out_conv=[32, 15])
+    net.apply(C2S.weight_init)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    cfg = O.BackboneConfig()
+    dt = _cpu_steps(O, sd, cfg, B, T, H, W, 1, 3)
+    dt_c1 = _cpu_steps(O, sd, cfg, 2, 16, 128, 128, 1, 3)
     return {"value": B / dt, "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"1 train step (fwd+CE+bwd+Adam, train mode) of the CPU oracle, U-TAE B={B} T={T} {H}x{W} fp32, "
-                      f"{dt:.1f} s on {threads} threads"}
+            "sample": f"CPU oracle (torch CPU restatement of the reference, validated against it), U-TAE train step "
+                      f"(fwd+CE+bwd+Adam, train mode) B={B} T={T} {H}x{W} fp32: 1 warm-up + 3 timed steps, {dt:.2f} s/step on "
+                      f"{threads} threads",
+            "configs0_value": 2 / dt_c1,
+            "configs0_sample": f"BASELINE.json configs[0]: U-TAE B=2 T=16 128x128, 1 warm-up + 3 timed steps, {dt_c1:.2f} s/step"}
 
 
 def main():
@@ -93,6 +110,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="patches per GPU")
     ap.add_argument("--T", type=int, default=32)
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--irregular", dest="irregular", action="store_true", default=None,
+                    help="pad_collate-style batch: series lengths T_b ~ U{27..T}, frames t >= T_b zero in x and dates "
+                         "(default for --model timeunet: BASELINE.json configs[2] is defined on it)")
+    ap.add_argument("--regular", dest="irregular", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3"],
@@ -123,6 +144,7 @@ def main():
     import crop2seg_amd as C2S
     from crop2seg_amd import engine as E
     from crop2seg_amd.learning.utils import TrainStep, default_config, get_model
+    from crop2seg_amd.learning.synthetic import synthetic_batch
 
     if args.conv_mode is not None:
         E.CONV_MODE = args.conv_mode
@@ -132,7 +154,8 @@ def main():
     net.train()
     step = TrainStep(net, num_classes=15, distributed=distributed)
     B, T, H = args.batch, args.T, args.size
-    x, dates, y = synthetic_batch(B, T, H, H, 1 + rank, device)
+    irregular = args.irregular if args.irregular is not None else args.model == "timeunet"
+    x, dates, y, lengths = synthetic_batch(B, T, H, H, 1 + rank, device, irregular=irregular)
 
     def barrier():
         if distributed:
@@ -154,7 +177,7 @@ def main():
     # HIP-event timing of the dominant kernel inside the timed region
     # (eager launches only: a captured graph cannot carry the timing events; bench_roofline() below measures the
     # same launches eagerly right after the timed region in graph mode)
-    E.PROFILE = {"match": dict(KH=3, S=1, C0=64, C1=0, Cout=64, Hin=H, N=B * T, reflect_adjoint=0), "events": []} if not use_graph else None
+    E.PROFILE = {"match": dict(KH=3, S=1, C0=64, C1=0, Cout=64, Hin=H, N=B * T, reflect_adjoint=0), "events": [], "ltae_events": []} if not use_graph else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = run()
@@ -168,7 +191,7 @@ def main():
     if use_graph:
         # roofline of the dominant kernel: the same launches, timed with HIP events on the launch stream during
         # extra eager steps (identical kernels, shapes and data as inside the graph)
-        prof = {"match": dict(KH=3, S=1, C0=64, C1=0, Cout=64, Hin=H, N=B * T, reflect_adjoint=0), "events": []}
+        prof = {"match": dict(KH=3, S=1, C0=64, C1=0, Cout=64, Hin=H, N=B * T, reflect_adjoint=0), "events": [], "ltae_events": []}
         E.PROFILE = prof
         for _ in range(3):
             step(x, dates, y)
@@ -185,26 +208,49 @@ def main():
     if rank == 0:
         ms = [a.elapsed_time(b) for a, b in prof["events"]]
         kernel_ms = sum(ms) / max(len(ms), 1)
-        flops_launch = 2.0 * (B * T) * 64 * 64 * 9 * H * H           # algorithmic FLOPs of one launch
-        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12 if ms else 0.0
+        N = B * T
+        flops_algo = 2.0 * N * 64 * 64 * 9 * H * H                    # direct-convolution FLOPs of one launch
         wino = E.WINOGRAD and E.CONV_MODE == "f32"
-        full = B * T == 128 and H == 128
+        # FLOPs the kernel actually issues on the MFMA pipe: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 output block
+        # where the direct form needs 36 -- the roofline fraction is priced on the EXECUTED count (<= 1 by construction)
+        flops_exec = flops_algo * (16.0 / 36.0 if wino else 1.0)
+        achieved = flops_exec / (kernel_ms * 1e-3) / 1e12 if ms else 0.0
+        kname = "conv_winograd_kernel<4,false>" if wino else "conv_igemm_kernel<3,1,2,false>"
+        traffic, traffic_src = dominant_traffic(kname, N, H)
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_F32_TFLOPS,
-                    "traffic": (DOMINANT_KERNEL_TRAFFIC_BYTES if wino else DOMINANT_KERNEL_TRAFFIC_BYTES_DIRECT) if full else None,
-                    "kernel": ("conv_winograd_kernel<4,*>" if wino else "conv_igemm_kernel<3,1,2,*>") +
-                              " 64->64 3x3 reflect @128x128 (forward launches; the data-gradient launches of the same kernel share the GPU "
-                              "with the weight gradients of the side stream, so their event-to-event time is not the kernel's own)",
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": 2.0 * N * 64 * H * H * 4 + 64 * 64 * 9 * 4,
+                    "kernel": kname + f" 64->64 3x3 reflect @{H}x{H}, N={N} frames (forward launches of the in_conv block; the "
+                              "data-gradient launches of the same kernel share the GPU with the weight gradients of the side "
+                              "stream, so their event-to-event time is not the kernel's own)",
                     "launches_timed": len(ms), "avg_launch_ms": kernel_ms,
-                    "algorithmic_flops_per_launch": flops_launch}
-        if wino:
-            # `achieved` is the ALGORITHMIC (direct-convolution) FLOP count of SURVEY.md 8d over the launch time; the
-            # Winograd F(2x2,3x3) kernel executes 16/36 of those multiplies on the MFMA pipe, so frac may exceed 1.
-            roofline["executed_flops_per_launch"] = flops_launch * 16.0 / 36.0
-            roofline["executed_tflops"] = achieved * 16.0 / 36.0
-            roofline["executed_frac_of_peak"] = achieved * 16.0 / 36.0 / PEAK_F32_TFLOPS
-            roofline["note"] = ("fp32 Winograd F(2x2,3x3): achieved = algorithmic direct-convolution FLOPs / time; "
-                                "executed_* = MFMA FLOPs actually issued (2.25x fewer)")
+                    "executed_flops_per_launch": flops_exec,
+                    "algorithmic_flops_per_launch": flops_algo,
+                    "algorithmic_tflops": flops_algo / (kernel_ms * 1e-3) / 1e12 if ms else 0.0,
+                    "note": ("achieved/frac = MFMA FLOPs the kernel executes (fp32 Winograd F(2x2,3x3): 16/36 of the direct-"
+                             "convolution count) / launch time / fp32 MFMA peak; algorithmic_tflops prices the same time with the "
+                             "direct-convolution FLOPs of SURVEY.md 8d" if wino else
+                             "direct implicit GEMM: executed = algorithmic FLOPs")}
+        lt = prof.get("ltae_events") or []
+        ltae_roofline = None
+        if lt and args.model == "timeunet":
+            lms = [a.elapsed_time(b) for a, b in lt]
+            lavg = sum(lms) / len(lms)
+            Ppix = B * H * H
+            lbytes = 4.0 * (Ppix * T * 64 + Ppix * 256 + 2 * 16 * Ppix * T)     # x read; emb, attn, attn_pre written
+            ltae_roofline = {"bound": "hbm", "achieved": lbytes / (lavg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                             "frac": lbytes / (lavg * 1e-3) / 8e12, "traffic": None,
+                             "kernel": "ltae_stream_fwd (prep + streaming forward, one call)", "avg_launch_ms": lavg,
+                             "launches_timed": len(lms), "algorithmic_bytes_per_launch": lbytes}
+        a_, b_ = STEP_FLOPS[args.model]
+        step_flops = (a_ * T + b_) * H * H * 3.0
+        cfg_id = {("utae", 4, 32, 128): "BASELINE.json configs[1] shape (fp32 instead of the bf16 named there: the reference is fp32-only)",
+                  ("timeunet", 8, 61, 128): "BASELINE.json configs[2] shape",
+                  ("wtae", 4, 32, 128): "BASELINE.json configs[3] per-GPU shape",
+                  ("utae", 8, 48, 256): "BASELINE.json configs[4] per-GPU shape"}.get((args.model, B, T, H), "off-BASELINE shape")
+        pad_note = (f"irregular series lengths T_b={lengths} (pad_collate zero padding of x and dates)" if irregular
+                    else "regular series (no temporal padding)")
         out = {
             "metric": "train patches/sec (Tx10x128x128) U-TAE" if args.model == "utae" else f"train patches/sec {args.model}",
             "value": world * B * args.steps / dt,
@@ -219,15 +265,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if E.CONV_MODE == "f32" else "bf16x3 (split-fp32 operands on bf16 MFMA, fp32 accumulate) + f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.model} train step (fwd+CE+bwd+Adam, train mode), B={B}/GPU T={T} 10x{H}x{H}, "
-                                   f"random-init weight_init weights, BASELINE.json configs[1] shape in fp32",
+            "config": {"workload": f"{args.model} train step (fwd+CE+bwd+Adam, train mode), B={B}/GPU T={T} 10x{H}x{H}, {pad_note}, "
+                                   f"weight_init random weights; {cfg_id}",
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}", "hipgraph": use_graph},
             "roofline": roofline,
             "loss": loss_val,
+            "step_mfma_frac": (world * B * args.steps / dt / world) * step_flops / (PEAK_F32_TFLOPS * 1e12),
         }
-        step_flops = {"utae": (182962 * T + 161216) * H * H * 3.0}.get(args.model)
-        if step_flops:
-            out["step_mfma_frac"] = (out["value"] / world) * step_flops / (PEAK_F32_TFLOPS * 1e12)
+        if ltae_roofline:
+            out["roofline_ltae"] = ltae_roofline
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
             try:
@@ -235,7 +281,10 @@ def main():
             except Exception:
                 pass
             threads = min(threads, args.cpu_threads)        # a 1-GPU box owns a 16-core share of the host
-            out["cpu_baseline"] = cpu_baseline(T, H, H, threads)
+            # BASELINE.json's metric is U-TAE's: the CPU leg always times the U-TAE step, at the bench shape when that is
+            # no larger than configs[1] (B=4, T=32, 128x128: ~25 s of CPU work), else at configs[1]
+            same = args.model == "utae" and B * T * H * H <= 4 * 32 * 128 * 128
+            out["cpu_baseline"] = cpu_baseline(*((B, T, H, H) if same else (4, 32, 128, 128)), threads)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

@@ -55,6 +55,7 @@ SZ = C.c_size_t
 SIGNATURES = {
     "c2s_abi_version": (I, []),
     "c2s_last_error": (C.c_char_p, []),
+    "c2s_init": (I, [I]),
     "c2s_device_cus": (I, []),
     "c2s_pack_weights": (I, [P, P, I, I, I, I, L, L, C.POINTER(I), P]),
     "c2s_pack_job_bytes": (SZ, []),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "c2s_ltae_fold_bwd_workspace_floats": (SZ, []),
     "c2s_ltae_fwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_fwd_ws": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P, SZ, P]),
+    "c2s_ltae_uses_streaming": (I, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_bwd": (I, [C.POINTER(LtaeDesc)] + [P] * 22 + [SZ, P]),
     "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P, P]),
@@ -127,6 +129,18 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _LIB = handle
     return _LIB
+
+
+_INITED = set()
+
+
+def init_device(index: int) -> None:
+    """c2s_init() for HIP device `index` (must be the current device): raises the kernels' dynamic-LDS limits and caches
+    the CU count before any launch -- in particular before a hipGraph capture."""
+    if index in _INITED:
+        return
+    check(lib().c2s_init(index), "c2s_init")
+    _INITED.add(index)
 
 
 def check(rc: int, what: str) -> None:

@@ -10,6 +10,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void c2s_set_error(const char* fmt, ...);
 
+// Per-device one-time set-up (misc.hip).  Every source file registers a hook that raises the dynamic-LDS limit of its
+// kernels; c2s_init(device) / c2s_ensure_init() run all hooks once per device under a mutex and cache the device's CU
+// count.  Entry points call c2s_ensure_init() (one thread-local hipGetDevice + an atomic load when already done), so a
+// caller that ran c2s_init() before capturing a hipGraph never triggers set-up work inside the capture.
+typedef void (*c2s_init_hook)(void);
+struct C2sInitRegistrar {
+    explicit C2sInitRegistrar(c2s_init_hook hook);
+};
+void c2s_ensure_init();
+int c2s_cus();   // compute units of the current device (256 when no device is present: CPU-side argument checks)
+#define C2S_RAISE_LDS(kernel) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+
 #define C2S_REQUIRE(cond, ...)            \
     do {                                  \
         if (!(cond)) {                    \

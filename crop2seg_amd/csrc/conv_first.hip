@@ -180,12 +180,7 @@ extern "C" int c2s_conv3x3_smallcin(const c2s_conv_desc* d, const float* src, co
     const long nt = (long)d->N * p.tiles_x * p.tiles_y;
     C2S_REQUIRE(nt < (1L << 30), "conv3x3_smallcin: too many tiles");
     p.ntiles = (int)nt;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = c2s_cus();
     const int wgs = (int)(nt < 2L * cus ? nt : 2L * cus);
     const dim3 grid(wgs, d->CoutP / 64);
     hipStream_t st = (hipStream_t)stream;

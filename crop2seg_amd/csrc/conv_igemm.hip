@@ -322,17 +322,24 @@ int launch_conv(const ConvParams& p, int N, int tiles, hipStream_t st) {
     const int FC = 1 << p.log2fc, FR = 32 >> p.log2fc;
     const int rows = (8 * FR - 1) * S + K, cols = (FC - 1) * S + K;
     const size_t lds = 2 * ((((size_t)CK * rows * cols + 3) & ~(size_t)3) + (size_t)NT * CK * 32 * MF) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<K, S, MF, ADJ>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     dim3 grid(tiles, p.CoutP / (32 * MF), N);
     hipLaunchKernelGGL((conv_igemm_kernel<K, S, MF, ADJ>), grid, dim3(256), lds, st, p);
     C2S_CHECK_LAUNCH("conv_igemm");
     return C2S_OK;
 }
+
+void init_hook() {
+#define C2S_RAISE4(K_, S_)                               \
+    C2S_RAISE_LDS((conv_igemm_kernel<K_, S_, 1, false>)); \
+    C2S_RAISE_LDS((conv_igemm_kernel<K_, S_, 2, false>));
+    C2S_RAISE4(3, 1) C2S_RAISE4(1, 1) C2S_RAISE4(2, 1) C2S_RAISE4(4, 2)
+#undef C2S_RAISE4
+    C2S_RAISE_LDS((conv_igemm_kernel<3, 1, 1, true>));
+    C2S_RAISE_LDS((conv_igemm_kernel<3, 1, 2, true>));
+    C2S_RAISE_LDS((conv_igemm_kernel<2, 1, 1, true>));
+    C2S_RAISE_LDS((conv_igemm_kernel<2, 1, 2, true>));
+}
+C2sInitRegistrar registrar(init_hook);
 
 }  // namespace
 
@@ -398,12 +405,7 @@ extern "C" int c2s_conv_igemm(const c2s_conv_desc* d, const float* src0, const f
     hipStream_t st = (hipStream_t)stream;
     // 64-channel tiles halve the LDS reads per MFMA, but on small planes (16x16 and below) they leave the grid short of
     // two workgroups per CU: fall back to 32-channel tiles there
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = c2s_cus();
     const bool wide = d->CoutP % 64 == 0 && (long)tiles * d->N * (d->CoutP / 64) >= 2L * cus;
 #define C2S_DISPATCH(K_, S_, A_)                                        \
     if (d->KH == K_ && d->S == S_ && (p.adj != 0) == A_)                \

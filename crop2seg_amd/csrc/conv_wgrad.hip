@@ -722,12 +722,7 @@ int launch_wgrad_tile(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
     p.ntiles = d->N * p.tiles_x * p.tiles_y;
     size_t fl = (size_t)CB * ((XR * XC) | 1) + (size_t)64 * (TP + 1);
     if (fl < 2 * 16 * 64) fl = 2 * 16 * 64;                       // exchange area of the position halves
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tile_kernel<K, S, LW, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    c2s_ensure_init();
     dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
     hipLaunchKernelGGL((conv_wgrad_tile_kernel<K, S, LW, MODE>), grid, dim3(256), fl * sizeof(float), st, p);
     C2S_CHECK_LAUNCH("conv_wgrad_tile");
@@ -754,12 +749,7 @@ int launch_wgrad(const c2s_wgrad_desc* d, WgradParams& p, hipStream_t st) {
     const int PC = 1 << p.log2pc, PR = C::TP >> p.log2pc;
     const int plane = ((PR - 1) * S + K) * ((PC - 1) * S + K);
     const size_t lds = ((size_t)32 * (plane | 1) + (size_t)64 * (C::TP + 1)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<K, S>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    c2s_ensure_init();
     dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
     hipLaunchKernelGGL((conv_wgrad_kernel<K, S>), grid, dim3(256), lds, st, p);
     C2S_CHECK_LAUNCH("conv_wgrad");
@@ -773,6 +763,20 @@ int check(const c2s_wgrad_desc* d) {
     C2S_REQUIRE(d->Hin < 1024 && d->Win < 1024, "wgrad: plane too large");
     return C2S_OK;
 }
+
+void init_hook() {
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<3, 1, 5, 2>));
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<3, 1, 5, 1>));
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<3, 1, 4, 1>));
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<1, 1, 5, 1>));
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<1, 1, 4, 1>));
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<4, 2, 5, 0>));
+    C2S_RAISE_LDS((conv_wgrad_tile_kernel<4, 2, 4, 0>));
+    C2S_RAISE_LDS((conv_wgrad_kernel<3, 1>));
+    C2S_RAISE_LDS((conv_wgrad_kernel<1, 1>));
+    C2S_RAISE_LDS((conv_wgrad_kernel<4, 2>));
+}
+C2sInitRegistrar registrar(init_hook);
 
 }  // namespace
 

@@ -458,6 +458,16 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
     }
 }
 
+void init_hook() {
+    C2S_RAISE_LDS((conv_winograd_kernel<4, false>));
+    C2S_RAISE_LDS((conv_winograd_kernel<4, true>));
+    C2S_RAISE_LDS((conv_winograd_kernel<3, false>));
+    C2S_RAISE_LDS((conv_winograd_kernel<3, true>));
+    C2S_RAISE_LDS((conv_winograd_kernel<2, false>));
+    C2S_RAISE_LDS((conv_winograd_kernel<2, true>));
+}
+C2sInitRegistrar registrar(init_hook);
+
 }  // namespace
 
 extern "C" size_t c2s_winograd_packed_floats(int cin, int coutP) {
@@ -536,18 +546,7 @@ extern "C" int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, c
     const int plane = (2 * BR + 2) * (2 * BC + 2);
     size_t fl = 2 * ((size_t)WN_CK * plane + WN_USLAB);
     if (fl < (size_t)WN_EXCH) fl = WN_EXCH;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_winograd_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    const int cus = c2s_cus();
     // persistent workgroups: two per CU (register / LDS limit), split over the output-channel blocks
     const int cblocks = d->CoutP / 64;
     const long ntotal = (long)d->N * p.tiles;

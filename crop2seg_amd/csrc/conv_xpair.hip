@@ -274,12 +274,7 @@ extern "C" int c2s_conv_xpair(const c2s_conv_desc* d, const float* src, const fl
     p.tiles_x = cdiv(d->Wout, FC);
     const int tiles = p.tiles_x * cdiv(d->Hout, 4 * FR);
     hipStream_t st = (hipStream_t)stream;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = c2s_cus();
     const bool wide = d->CoutP % 64 == 0 && (long)tiles * d->N * (d->CoutP / 64) >= 2L * cus;
     if (d->reflect_adjoint)
         return wide ? launch_xpair<2, true>(p, d->N, tiles, st) : launch_xpair<1, true>(p, d->N, tiles, st);

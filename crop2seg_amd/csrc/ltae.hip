@@ -1657,6 +1657,15 @@ void fill(LtaeParams& p, const c2s_ltae_desc* d) {
     p.keep = d->keep;
 }
 
+void init_hook() {
+    C2S_RAISE_LDS(ltae_fwd_kernel);
+    C2S_RAISE_LDS(ltae_bwd_heads_kernel);
+    C2S_RAISE_LDS(ltae_bwd_gx_kernel);
+    C2S_RAISE_LDS(ltae_stream_bwd_heads_kernel<4>);
+    C2S_RAISE_LDS(ltae_stream_bwd_gx_kernel<4>);
+}
+C2sInitRegistrar registrar(init_hook);
+
 }  // namespace
 
 #ifdef C2S_LT_STAMP
@@ -1675,14 +1684,11 @@ extern "C" size_t c2s_ltae_fwd_workspace_floats(const c2s_ltae_desc* d) {
 
 // The streaming kernels pay off once the 64-pixel tiles fill the chip; below that the 16-pixel LDS kernel is used.
 static bool use_stream(const c2s_ltae_desc* d) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = c2s_cus();
     return d->C == 64 && (long)d->B * ((d->HW + 63) / 64) >= 2L * cus;
 }
+
+extern "C" int c2s_ltae_uses_streaming(const c2s_ltae_desc* d) { return d && check(d) == C2S_OK && use_stream(d) ? 1 : 0; }
 
 extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                                     const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
@@ -1706,12 +1712,7 @@ extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, cons
         C2S_CHECK_LAUNCH("ltae_stream_fwd");
         return C2S_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr_set = true;
-    }
+    c2s_ensure_init();
     hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * ((d->HW + 15) / 16)), dim3(256), fwd_lds(d), st, p);
     C2S_CHECK_LAUNCH("ltae_fwd");
     return C2S_OK;
@@ -1760,14 +1761,7 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     p.part_bc = p.part_s0 + tiles_ws * d->T * NH;
     p.part_gb = p.part_bc + tiles_ws * 256;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_bwd_gx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_stream_bwd_heads_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ltae_stream_bwd_gx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    c2s_ensure_init();
     StreamBwd sb = {};
     if (stream_path) {
         // the V area of the workspace is not used by the streaming kernels: it holds M [P][16][2] and part_U [tiles][16][C]

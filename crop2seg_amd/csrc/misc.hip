@@ -1,6 +1,9 @@
 // Small kernels of the hot path: frame flags, depthwise convolution (W-TAE), cross-entropy, flat Adam,
 // fill / add.  All HBM- or latency-bound; see DESIGN.md for the per-kernel roofline notes.
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -14,12 +17,61 @@ void c2s_set_error(const char* fmt, ...) {
 
 extern "C" int c2s_abi_version(void) { return 1; }
 extern "C" const char* c2s_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- per-device one-time set-up
+namespace {
+constexpr int kMaxDevices = 64;
+struct InitState {
+    std::mutex mu;
+    std::vector<c2s_init_hook> hooks;
+    std::atomic<uint64_t> done{0};          // bit d: device d is set up
+    int cus[kMaxDevices] = {};
+};
+InitState& init_state() {
+    static InitState* s = new InitState();   // construct on first use (registrars run during static initialisation)
+    return *s;
+}
+int init_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    InitState& s = init_state();
+    if (s.done.load(std::memory_order_acquire) >> dev & 1) return dev;
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (s.done.load(std::memory_order_relaxed) >> dev & 1) return dev;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    s.cus[dev] = cus;
+    for (c2s_init_hook h : s.hooks) h();
+    (void)hipGetLastError();
+    s.done.fetch_or(1ull << dev, std::memory_order_release);
+    return dev;
+}
+}  // namespace
+
+C2sInitRegistrar::C2sInitRegistrar(c2s_init_hook hook) { init_state().hooks.push_back(hook); }
+void c2s_ensure_init() { (void)init_current_device(); }
+int c2s_cus() {
+    const int dev = init_current_device();
+    return dev < 0 ? 256 : init_state().cus[dev];
+}
+
+extern "C" int c2s_init(int device) {
+    int cur = -1;
+    C2S_REQUIRE(hipGetDevice(&cur) == hipSuccess, "c2s_init: no HIP device");
+    C2S_REQUIRE(device < 0 || device == cur, "c2s_init: device %d is not the current device (%d); make it current first", device, cur);
+    C2S_REQUIRE(init_current_device() >= 0, "c2s_init: device index out of range");
+    return C2S_OK;
+}
 extern "C" int c2s_device_cus(void) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    return prop.multiProcessorCount;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return c2s_cus();
 }
 
 namespace {

@@ -50,6 +50,10 @@ class Workspace:
 
     def __init__(self, device):
         self.device = device
+        if getattr(device, "type", None) == "cuda":
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            with torch.cuda.device(idx):
+                _lib.init_device(idx)              # one-time per device, before any launch or hipGraph capture
         self.bufs: Dict[str, Tensor] = {}
         # weight-pack plan: the jobs recorded during one step become a device table that later steps run in one launch
         self.pack_record: Dict[Tuple, Tuple] = {}
@@ -688,10 +692,18 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     stats = torch.empty(B * HW * n_head * 2, device=x5.device, dtype=torch.float32)
     Ud, s0d = U, s0
     fws = ctx.ws.get("ltae_fwd", lib().c2s_ltae_fwd_workspace_floats(C.byref(d)))
+    prof = PROFILE
+    timed = prof is not None and "ltae_events" in prof
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().c2s_ltae_attn_fwd_ws(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
                                      s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
                                      attn.data_ptr(), _ptr(attn_pre), _ptr(emb), stats.data_ptr(), fws.data_ptr(),
                                      fws.numel(), _stream()), "ltae_fwd")
+    if timed:
+        e1.record()
+        prof["ltae_events"].append((e0, e1))
     if ctx.tape is None:
         return emb, attn
     tape = ctx.tape

@@ -8,7 +8,7 @@ This module has no HIP dependency so that the N > 1 logic is testable without a 
 from __future__ import annotations
 
 import os
-from typing import Optional
+from typing import Iterable, Optional
 
 import torch
 import torch.distributed as dist
@@ -22,9 +22,22 @@ class FlatDataParallel:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
 
-    def sync_parameters(self, flat_param: torch.Tensor, src: int = 0) -> None:
-        """Identical initial weights on every rank (DDP semantics)."""
+    def sync_parameters(self, flat_param: torch.Tensor, buffers: Optional[Iterable[torch.Tensor]] = None, src: int = 0) -> None:
+        """Identical initial state on every rank (DDP semantics: torch's DistributedDataParallel broadcasts rank 0's
+        parameters AND buffers at construction): the flat parameter buffer in one collective, the BatchNorm buffers
+        (running_mean / running_var / num_batches_tracked -- a few hundred floats) coalesced into one more."""
         dist.broadcast(flat_param, src=src, group=self.group)
+        bufs = [b for b in (buffers or []) if b is not None and b.numel() > 0]
+        if not bufs:
+            return
+        # one flat fp64 staging tensor: exact for fp32 statistics and for int64 counters below 2^53
+        flat = torch.cat([b.detach().to(torch.float64).flatten() for b in bufs])
+        dist.broadcast(flat, src=src, group=self.group)
+        off = 0
+        for b in bufs:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view_as(b).to(b.dtype))
+            off += n
 
     def reduce_gradients(self, flat_grad: torch.Tensor) -> float:
         """Sum the flat gradient buffer over ranks in place; returns the scale (1/world) the optimiser must apply

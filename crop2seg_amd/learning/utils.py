@@ -115,7 +115,8 @@ class TrainStep:
         if distributed:
             from .ddp import FlatDataParallel
             self.dp = FlatDataParallel(process_group)
-            self.dp.sync_parameters(self.flat_param)                      # identical initial weights on every rank
+            # identical initial weights AND BatchNorm buffers on every rank
+            self.dp.sync_parameters(self.flat_param, [b for _, b in model.named_buffers()])
 
     # ------------------------------------------------------------------------------------------------
     def _forward_backward(self, x: Tensor, dates: Tensor, y: Tensor, drop: Fn.DropoutState) -> Tuple[Tensor, Tensor]:

@@ -12,7 +12,10 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *   - entry points never allocate, never synchronise and never throw: they validate their arguments,
  *     enqueue kernels on `stream` and return C2S_OK or a negative C2S_E* code, so a sequence of calls
- *     is hipGraph-capturable; scratch memory is caller-provided (query with the *_workspace_floats calls);
+ *     is hipGraph-capturable PROVIDED c2s_init() ran on the device beforehand (it raises the dynamic-LDS
+ *     limits of the kernels and caches the CU count; an entry point that finds its device not set up does
+ *     that set-up itself -- thread-safe, once per device -- which is not legal inside a stream capture);
+ *     scratch memory is caller-provided (query with the *_workspace_floats calls);
  *   - `valid` is an int32[N] per-frame flag array (1 = real frame, 0 = temporal padding) or NULL when
  *     every frame is real; padded frames are skipped (reference: temp_shared_block.py:31-40).
  */
@@ -39,6 +42,10 @@ extern "C" {
 
 int c2s_abi_version(void);
 const char* c2s_last_error(void);
+/* One-time set-up of the CURRENT device (pass its index, or -1 for "whichever is current"): function attributes
+ * (160 KB dynamic LDS) and the cached CU count.  Idempotent and thread-safe; call it once per device before capturing
+ * a hipGraph.  Build-defined (the reference has no counterpart: torch initialises its kernels lazily). */
+int c2s_init(int device);
 /* number of compute units of the current device (for split-K sizing); <=0 on error */
 int c2s_device_cus(void);
 
@@ -259,6 +266,9 @@ int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* ga
                          const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
                          const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
                          float* workspace, size_t ws_floats, void* stream);
+/* 1 when this shape runs the streaming kernels on the current device (forward: with a workspace and attn_pre;
+ * backward: additionally needs g_emb), 0 for the 16-/8-pixel LDS kernels.  Lets tests assert which path they cover. */
+int c2s_ltae_uses_streaming(const c2s_ltae_desc* d);
 size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
 /* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],
  * gU [16,C], gs0 [B,T,16], gWc [256,C] (embedding path only), gbc [256], ggamma [C], gbeta [C]. */

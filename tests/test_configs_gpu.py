@@ -1,0 +1,217 @@
+"""GPU parity + property tests at the shapes BASELINE.json names (configs[1..4]) -- the kernels those workloads
+actually run, with the temporal padding real batches always carry.
+
+* TimeUNet at a size that routes the L-TAE to the STREAMING kernels, whole model, eval and train mode, against the
+  CPU oracle (fp64-anchored criterion of SURVEY.md 8c.4 for the gradients).
+* One train-mode forward + backward per BASELINE config at the per-GPU size (C5 at reduced B): size-independent
+  properties (attention sums to 1, exactly zero attention and exactly pad_value features on padded frames, finite and
+  non-trivial gradients, batch independence bit for bit) and agreement of the two exact-fp32 convolution algorithms
+  (Winograd F(2x2,3x3) vs direct implicit GEMM).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import crop2seg_oracle as O  # noqa: E402
+from oracle import seeded  # noqa: E402
+
+
+def _mods():
+    import crop2seg_amd as C2S
+    from crop2seg_amd import _lib
+    from crop2seg_amd import engine as E
+    from crop2seg_amd.backbones import functional as Fn
+    from crop2seg_amd.learning import utils as LU
+    from crop2seg_amd.learning.synthetic import synthetic_batch
+    return C2S, _lib, E, Fn, LU, synthetic_batch
+
+
+def _streams(B, T, C, HW):
+    _, L, _, _, _, _ = _mods()
+    d = L.LtaeDesc(B, T, C, HW, 16, 256, 1e-5, 0.0, 0, None, None)
+    return bool(L.lib().c2s_ltae_uses_streaming(C.byref(d)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# TimeUNet through the streaming L-TAE kernels vs the CPU oracle
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("training", [False, True])
+def test_timeunet_streaming_matches_oracle(training):
+    C2S, L, E, Fn, LU, _ = _mods()
+    B, T, H = 2, 8, 128
+    assert _streams(B, T, 64, H * H), "this size must route the L-TAE to the streaming kernels"
+    net = C2S.TimeUNet_v1(input_dim=10, out_conv=[32, 15])
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = seeded.make_state(ks, 32, "tame")
+    net.load_state_dict(sd)
+    net = net.cuda().train(training)
+    net.spec.attn_dropout = 0.0
+    net.spec.mlp_dropout = 0.0
+    x, dates, y = seeded.make_inputs(B, T, 10, H, H, 5, [8, 6])
+    cfg = O.BackboneConfig(model="timeunet")
+    ref_logits, ref_loss, g32, bn = O.loss_and_grads(sd, x, dates, y, cfg, training)
+    with torch.no_grad():
+        _, ref_att = O.forward(sd, x, dates, cfg, training=training)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, _, g64, _ = O.loss_and_grads(sd64, x.double(), dates, y, cfg, training)
+
+    logits, att = net(x.cuda(), batch_positions=dates.cuda(), return_att=True)
+    scale = float(ref_logits.abs().max())
+    assert float((logits.detach().cpu() - ref_logits).abs().max()) <= 1e-3 * scale
+    assert float((att.detach().cpu() - ref_att).abs().max()) <= 1e-4
+    assert float(att[:, 1, 6:].abs().max()) == 0.0                # padded frames of sample 1
+    if not training:
+        # argmax bit-exact wherever the oracle's own top-2 margin is above fp32 evaluation noise
+        top2 = ref_logits.topk(2, dim=1).values
+        decided = (top2[:, 0] - top2[:, 1]) > 1e-4 * scale
+        assert torch.equal(logits.argmax(1).cpu()[decided], ref_logits.argmax(1)[decided])
+        assert float(decided.float().mean()) > 0.5
+    wgt = torch.ones(15, device="cuda")
+    wgt[-1] = 0
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda(), weight=wgt)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+    loss.backward()
+    params = dict(net.named_parameters())
+    gmax = max(float(v.norm()) for v in g64.values())
+    worst = (0.0, "")
+    for n, ref in g64.items():
+        got = params[n].grad.detach().double().cpu()
+        err = float((got - ref).norm())
+        err32 = float((g32[n].double() - ref).norm())
+        sc = float(ref.norm())
+        # err(impl, fp64) <= max(3 err(oracle fp32, fp64), 1e-3 scale) (+ absolute floor for structurally-zero gradients)
+        assert err <= max(3 * err32, 1e-3 * sc) + 2e-5 * gmax, (n, err / max(sc, 1e-30), err32 / max(sc, 1e-30))
+        if sc > 1e-4 * gmax:
+            worst = max(worst, (err / sc, n))
+    print(f"timeunet streaming ({'train' if training else 'eval'}): worst gradient error vs fp64 {worst[0]:.2e} ({worst[1]})")
+    if training:
+        sdn = net.state_dict()
+        for k, v in bn.updates.items():
+            if v.is_floating_point():
+                assert float((sdn[k].cpu() - v).abs().max()) <= 1e-4 * max(1.0, float(v.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# full per-GPU sizes of BASELINE configs[1..4]
+# ------------------------------------------------------------------------------------------------------------------
+FULL = [
+    # id, model, B, T, H, lengths (None = irregular T_b ~ U{27..T} as in README.md:92), flavour
+    ("C2_utae_b4_t32_128", "utae", 4, 32, 128, [32, 27, 32, 30]),
+    ("C3_timeunet_b8_t61_128", "timeunet", 8, 61, 128, None),
+    ("C4_wtae_b4_t32_128", "wtae", 4, 32, 128, [32, 32, 29, 27]),
+    ("C5_utae_b2_t48_256", "utae", 2, 48, 256, [48, 40]),       # configs[4] runs B = 8 per GPU; same kernels and planes at B = 2
+]
+
+
+def _model(model, flavour="wi", seed=1):
+    C2S, L, E, Fn, LU, _ = _mods()
+    torch.manual_seed(seed)
+    net = LU.get_model(LU.default_config(model))
+    if flavour == "wi":
+        net.apply(C2S.weight_init)
+    else:
+        ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        net.load_state_dict(seeded.make_state(ks, 40 + seed, "tame"))
+    return net.cuda()
+
+
+@pytest.mark.parametrize("cid,model,B,T,H,lengths", FULL, ids=[f[0] for f in FULL])
+def test_full_size_train_properties(cid, model, B, T, H, lengths):
+    C2S, L, E, Fn, LU, synthetic_batch = _mods()
+    x, dates, y, lengths = synthetic_batch(B, T, H, H, 1, "cuda", irregular=lengths is None, lengths=lengths)
+    if model == "timeunet":
+        assert _streams(B, T, 64, H * H) and max(lengths) == T and min(lengths) < T
+    net = _model(model).train()
+    net.spec.attn_dropout = 0.0            # attention is returned post-dropout: the sum-to-one property needs p = 0
+    net.spec.mlp_dropout = 0.0
+    logits, att = net(x, batch_positions=dates, return_att=True)
+    h = H if model == "timeunet" else H // 8
+    assert logits.shape == (B, 15, H, H) and att.shape == (16, B, T, h, h)
+    assert bool(torch.isfinite(logits).all()) and float(logits.min()) >= 0.0        # BN + ReLU head (utae.py:191)
+    assert float((att.sum(dim=2) - 1).abs().max()) < 2e-5
+    for b, tb in enumerate(lengths):
+        if tb < T:
+            assert float(att[:, b, tb:].abs().max()) == 0.0, "padded frames must get exactly zero attention"
+        assert float(att[:, b, :tb].max()) > 0.0
+    wgt = torch.ones(15, device="cuda")
+    wgt[-1] = 0
+    loss = torch.nn.functional.cross_entropy(logits, y, weight=wgt)
+    loss.backward()
+    assert bool(torch.isfinite(loss))
+    nonzero = 0
+    for n, p in net.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        nonzero += int(float(p.grad.abs().max()) > 0)
+    assert nonzero >= 0.9 * len(list(net.parameters()))
+    # batch independence of everything upstream of the decoder's BatchNorm: the attention masks of sample 1 computed
+    # alone are bit-identical to those computed inside the batch (GroupNorm encoder + per-pixel L-TAE)
+    del logits, loss
+    with torch.no_grad():
+        _, a1 = net(x[1:2].contiguous(), batch_positions=dates[1:2].contiguous(), return_att=True)
+    assert torch.equal(a1[:, 0], att[:, 1])
+
+
+@pytest.mark.parametrize("cid,model,B,T,H,lengths", FULL[:3], ids=[f[0] for f in FULL[:3]])
+def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths):
+    """The Winograd F(2x2,3x3) kernels (forward, data gradient, weight gradient) and the direct implicit-GEMM kernels are
+    two exact-fp32 evaluations of the same step: loss, logits and every parameter gradient must agree at the full size,
+    padded frames included.  Tame weights: under weight_init's N(0,1) BatchNorm gains whole channels sit on the ReLU
+    kink and two valid fp32 evaluation orders legitimately differ by 1e-2 on single tensors."""
+    C2S, L, E, Fn, LU, synthetic_batch = _mods()
+    x, dates, y, lengths = synthetic_batch(B, T, H, H, 1, "cuda", irregular=lengths is None, lengths=lengths)
+    results = {}
+    old = E.WINOGRAD
+    try:
+        for wino in (True, False):
+            E.WINOGRAD = wino
+            net = _model(model, "tame").train()
+            net.spec.attn_dropout = 0.0
+            net.spec.mlp_dropout = 0.0
+            step = LU.TrainStep(net, num_classes=15)
+            loss, logits = step(x, dates, y, apply_update=False)
+            torch.cuda.synchronize()
+            results[wino] = (float(loss), logits.clone(), step.flat_grad.clone(), {n: g.clone() for n, g in step.grads.items()})
+            del step, net
+    finally:
+        E.WINOGRAD = old
+    (l1, lg1, f1, g1), (l0, lg0, f0, g0) = results[True], results[False]
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    assert float((lg1 - lg0).abs().max()) <= 1e-4 * float(lg0.abs().max())
+    flat_rel = float((f1 - f0).double().norm() / f0.double().norm())
+    gmax = max(float(g.norm()) for g in g0.values())
+    worst = (0.0, "")
+    for n in g0:
+        sc = float(g0[n].norm())
+        if sc > 1e-3 * gmax:
+            worst = max(worst, (float((g1[n] - g0[n]).norm()) / sc, n))
+    print(f"{cid}: winograd vs direct: loss {abs(l1 - l0) / abs(l0):.1e}, flat gradient {flat_rel:.1e}, worst tensor {worst[0]:.1e} ({worst[1]})")
+    assert flat_rel <= 1e-4
+    assert worst[0] <= 1e-3, worst
+
+
+def test_padded_frames_give_pad_value_features():
+    """smart_forward semantics at the full resolution (temp_shared_block.py:31-40): the encoder blocks emit exactly
+    pad_value on padded frames and the same values on real frames whether or not the batch contains padding."""
+    C2S, L, E, Fn, LU, synthetic_batch = _mods()
+    B, T, H = 2, 6, 128
+    x, dates, y, _ = synthetic_batch(B, T, H, H, 3, "cuda", lengths=[6, 4])
+    net = _model("utae").eval()
+    spec = net.spec
+    with torch.no_grad():
+        named = dict(net.named_parameters())
+        ctx = E.Ctx(named, dict(net.named_buffers()), None, E.Workspace(x.device), False, None)
+        valid = E.frame_flags(x, spec.pad_value)
+        assert valid.view(B, T).tolist() == [[1] * 6, [1, 1, 1, 1, 0, 0]]
+        f0 = Fn.conv_block(ctx, x.view(B * T, 10, H, H), "in_conv", 2, "group", spec, valid, need_input_grad=False)
+        f1 = Fn.down_conv_block(ctx, f0, "down_blocks.0", "group", spec, valid)
+        for f in (f0, f1):
+            f5 = f.view(B, T, *f.shape[1:])
+            assert float(f5[1, 4:].abs().max()) == 0.0
+            assert float(f5[1, :4].abs().max()) > 0.0
+        # the un-padded sample alone: identical features, bit for bit
+        x0 = x[:1].contiguous()
+        g0 = Fn.conv_block(ctx, x0.view(T, 10, H, H), "in_conv", 2, "group", spec, None, need_input_grad=False)
+        assert torch.equal(g0, f0[:T])

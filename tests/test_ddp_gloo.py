@@ -40,7 +40,11 @@ def _worker(rank, world, port, out_dir):
     sizes = [sd[n].numel() for n in names]
     flat_p = torch.cat([sd[n].flatten() for n in names])
     dp = FlatDataParallel()
-    dp.sync_parameters(flat_p)
+    bufs = [sd[k] for k in sd if k not in names]     # BatchNorm running statistics + step counters (differ per rank too)
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k].fill_(10 + rank)
+    dp.sync_parameters(flat_p, bufs)
     off = 0
     for n, s in zip(names, sizes):
         sd[n] = flat_p[off:off + s].view_as(sd[n]).clone()
@@ -52,7 +56,8 @@ def _worker(rank, world, port, out_dir):
     flat_g = torch.cat([grads[n].flatten() for n in names])
     local = flat_g.clone()
     scale = dp.reduce_gradients(flat_g)
-    torch.save({"flat_p": flat_p, "local": local, "reduced": flat_g, "scale": scale}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save({"flat_p": flat_p, "local": local, "reduced": flat_g, "scale": scale,
+                "bufs": torch.cat([b.double().flatten() for b in bufs])}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,6 +68,8 @@ def test_flat_gradient_allreduce_world2(tmp_path):
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["flat_p"], r1["flat_p"]), "parameters differ after the initial broadcast"
+    assert torch.equal(r0["bufs"], r1["bufs"]) and float(r0["bufs"].abs().sum()) > 0, "BatchNorm buffers differ after the broadcast"
+    assert float(r0["bufs"].max()) == 10.0, "num_batches_tracked must be rank 0's"
     assert r0["scale"] == 0.5 and r1["scale"] == 0.5
     assert torch.equal(r0["reduced"], r1["reduced"]), "ranks hold different reduced gradients"
     expect = r0["local"] + r1["local"]

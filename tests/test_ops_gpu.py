@@ -54,6 +54,11 @@ CONV_CASES = [
     (1, 24, 40, 24, 40, 3, 1, 1, "reflect"),      # ragged: sizes that are not powers of two
     (2, 4, 64, 16, 64, 3, 1, 1, "zeros"),         # few-input-channel kernel: 2 channel pairs, zero padding
     (3, 9, 128, 8, 32, 3, 1, 1, "reflect"),       # ... odd channel count, two blocks of 64 output channels, one tile per frame
+    # padded frame (valid[1] = 0) on the wide full-resolution kernels real batches run: Winograd forward / data / weight
+    # gradient (next_tile skip + XCD start permutation), and the 4x4 stride-2 forward + transposed-row data gradient
+    (3, 64, 64, 128, 128, 3, 1, 1, "reflect"),
+    (3, 64, 64, 64, 64, 4, 2, 1, "reflect"),
+    (5, 64, 64, 64, 64, 3, 1, 1, "reflect"),      # two padded frames (1 and 3): tiles of several skipped frames in a row
 ]
 
 
@@ -68,6 +73,8 @@ def test_conv2d_fwd_bwd(case):
     valid = torch.ones(N, dtype=torch.int32)
     if N >= 3:
         valid[1] = 0
+    if N >= 5:
+        valid[3] = 0
     keep = valid.bool()
     ref = O.conv2d(x[keep], w, b, S, pad, mode)
     gout = torch.randn(ref.shape, generator=g)
@@ -216,6 +223,10 @@ def _ltae_state(C, g, flavour="tame"):
     (1, 61, 64, 16, True, True, False),     # TimeUNet-like: T = 61
     (2, 5, 64, 128, True, True, True),      # 512 tiles of 64 pixels: the streaming kernels (TimeUNet resolution)
     (2, 4, 64, 128, False, False, False),   # streaming, attention masks only
+    # BASELINE configs[2] shape of the block (TimeUNet: T = 61, C = 64, 128x128 pixels per patch): the streaming kernels with
+    # every T-chunk loop iterated several times and the T-dependent dynamic LDS of the backward at its maximum
+    (2, 61, 64, 128, True, True, True),
+    (2, 61, 64, 128, True, False, False),
 ])
 def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     E, L = _engine()
@@ -226,9 +237,10 @@ def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     dates = (5 * torch.arange(T)[None] + torch.arange(B)[:, None]).long()
     valid = torch.ones(B, T, dtype=torch.int32)
     if pad:
-        valid[0, T - 2:] = 0
-        x[0, T - 2:] = 0
-        dates[0, T - 2:] = 0
+        tb = T - 2 if T < 20 else 27        # T = 61: the shortest series of the irregular-T range (reference README.md:92)
+        valid[0, tb:] = 0
+        x[0, tb:] = 0
+        dates[0, tb:] = 0
     P = B * h * h
     keep = (torch.rand(16, P, T, generator=g) >= 0.1).float() if drop else None
     x.requires_grad_(True)

@@ -99,3 +99,23 @@ def test_padded_frames_semantics():
     out = O.conv_block(x, sd, "in_conv", 2, "group", cfg, False, None, 0.0)
     assert torch.equal(out[0, 2], torch.zeros_like(out[0, 2]))
     assert out[0, :2].abs().sum() > 0
+
+
+def test_oracle_adam_matches_torch_optim():
+    """O.adam_step is the optimiser the HIP Adam kernel is judged against: pin it to torch.optim.Adam itself
+    (defaults of the reference's train.py:454: lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay)."""
+    g = torch.Generator().manual_seed(3)
+    shapes = {"a": (64, 10, 3, 3), "b": (64,), "c": (1000,)}
+    p_ref = {k: torch.nn.Parameter(torch.randn(s, generator=g)) for k, s in shapes.items()}
+    p = {k: v.detach().clone() for k, v in p_ref.items()}
+    m = {k: torch.zeros(s) for k, s in shapes.items()}
+    v = {k: torch.zeros(s) for k, s in shapes.items()}
+    opt = torch.optim.Adam(list(p_ref.values()), lr=1e-3)
+    for step in range(1, 8):
+        grads = {k: torch.randn(s, generator=g) * (10.0 ** (step % 3 - 1)) for k, s in shapes.items()}
+        for k in shapes:
+            p_ref[k].grad = grads[k].clone()
+        opt.step()
+        O.adam_step(p, grads, m, v, step)
+        for k in shapes:
+            assert float((p[k] - p_ref[k].detach()).abs().max()) <= 2e-7 * max(1.0, float(p_ref[k].abs().max())), (k, step)
