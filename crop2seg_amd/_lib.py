@@ -15,6 +15,7 @@ c_float_p = C.c_void_p   # device pointers are passed as integers (tensor.data_p
 c_int_p = C.c_void_p
 
 PAD_ZEROS, PAD_REFLECT = 0, 1
+SRC_F32, SRC_I16, SRC_U16 = 0, 1, 2
 NORM_GROUP, NORM_BATCH = 0, 1
 
 
@@ -97,11 +98,22 @@ SIGNATURES = {
     "c2s_pixel_gn_fwd": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "c2s_pixel_gn_bwd_workspace_floats": (SZ, [I, I, I]),
     "c2s_pixel_gn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "c2s_attn_head_mean": (I, [P, P, I, L, P]),
+    "c2s_attn_head_mean_bwd": (I, [P, P, I, L, I, P]),
+    "c2s_frame_mean_weights": (I, [P, P, I, I, I, P]),
     "c2s_temporal_aggregate_fwd": (I, [C.POINTER(AggDesc), P, P, P, P, P]),
     "c2s_temporal_aggregate_bwd_workspace_floats": (SZ, [C.POINTER(AggDesc)]),
     "c2s_temporal_aggregate_bwd": (I, [C.POINTER(AggDesc), P, P, P, P, P, I, P, P, SZ, P]),
     "c2s_cross_entropy_workspace_floats": (SZ, [I, I]),
-    "c2s_cross_entropy": (I, [P, P, P, P, P, I, I, I, P, SZ, P]),
+    "c2s_cross_entropy": (I, [P, P, P, P, P, I, I, I, F, C.c_longlong, P, SZ, P]),
+    "c2s_metrics_update": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "c2s_confusion_add": (I, [P, P, P, L, I, P]),
+    "c2s_loss_meter_add": (I, [P, P, P]),
+    "c2s_boundary_target": (I, [P, P, I, I, I, P]),
+    "c2s_focal_ce_workspace_floats": (SZ, []),
+    "c2s_focal_ce": (I, [P, P, P, P, I, I, I, F, C.c_longlong, I, P, SZ, P]),
+    "c2s_collate_series": (I, [P, I, P, P, P, P, P, I, I, I, I, I, C.POINTER(I), C.POINTER(F), C.POINTER(F), F, P]),
+    "c2s_softmax_stitch": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "c2s_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P, F, P]),
     "c2s_fill": (I, [P, L, F, P]),
     "c2s_add_inplace": (I, [P, P, L, P]),

@@ -36,6 +36,9 @@ class BackboneSpec:
     d_k: int = 4
     pad_value: float = 0.0
     padding_mode: str = "reflect"
+    add_boundary_loss: bool = False   # second (2-class) head on the last decoder map (reference utae.py:195-198,236-244)
+    encoder: bool = False             # return (last decoder map, maps) instead of logits (utae.py:233-234)
+    return_maps: bool = False         # also return the decoder feature maps (utae.py:224-231)
     pe_period: float = 1000.0
     attn_dropout: float = 0.1       # reference tae.py:816
     mlp_dropout: float = 0.2        # reference tae.py:361
@@ -124,11 +127,30 @@ def ltae(ctx, x5, dates, valid, prefix, spec: BackboneSpec, drop: DropoutState, 
     return o, attn
 
 
-def _decoder_and_head(ctx, out, skips, spec):
+@dataclass
+class BackboneOutput:
+    """What the reference's forward() can return (utae.py:233-252), before it is packed into a tuple."""
+    logits: Optional[Tensor]              # None with encoder=True
+    att: Tensor
+    boundary: Optional[Tensor] = None     # [B,2,H,W] logits of the boundary head
+    maps: Optional[List[Tensor]] = None   # decoder feature maps, coarsest first
+    last: Optional[Tensor] = None         # last decoder map (the `out` of encoder=True)
+
+
+def _decoder_and_head(ctx, out, skips, spec, att):
     n_stages = len(spec.encoder_widths)
+    maps = [out]
     for i in range(n_stages - 1):
         out = up_conv_block(ctx, out, skips[i], f"up_blocks.{i}", spec)
-    return conv_layer(ctx, [out], "out_conv.conv", len(spec.out_conv), "batch", 3, 1, 1, spec, None)
+        maps.append(out)
+    keep_maps = maps if (spec.return_maps or spec.encoder) else None
+    if spec.encoder:
+        return BackboneOutput(None, att, None, keep_maps, out)
+    logits = conv_layer(ctx, [out], "out_conv.conv", len(spec.out_conv), "batch", 3, 1, 1, spec, None)
+    boundary = None
+    if spec.add_boundary_loss:
+        boundary = conv_layer(ctx, [out], "boundary_conv.conv", 2, "batch", 3, 1, 1, spec, None)
+    return BackboneOutput(logits, att, boundary, keep_maps, out)
 
 
 def _fold(x5: Tensor) -> Tensor:
@@ -151,9 +173,9 @@ def utae_forward(ctx, spec, x5, dates, drop):
         f = down_conv_block(ctx, f, f"down_blocks.{i}", spec.encoder_norm, spec, valid)
         fmaps.append(f)
     out, att = ltae(ctx, _unfold(fmaps[-1], B, T), dates, valid, "temporal_encoder", spec, drop, True)
-    skips = [E.temporal_aggregate(ctx, _unfold(fmaps[-(i + 2)], B, T), att, valid, spec.n_head)
+    skips = [E.temporal_aggregate(ctx, _unfold(fmaps[-(i + 2)], B, T), att, valid, spec.n_head, spec.agg_mode)
              for i in range(n_stages - 1)]
-    return _decoder_and_head(ctx, out, skips, spec), att
+    return _decoder_and_head(ctx, out, skips, spec, att)
 
 
 def timeunet_forward(ctx, spec, x5, dates, drop):
@@ -167,7 +189,7 @@ def timeunet_forward(ctx, spec, x5, dates, drop):
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
-    return _decoder_and_head(ctx, fmaps[-1], skips, spec), att
+    return _decoder_and_head(ctx, fmaps[-1], skips, spec, att)
 
 
 def wtae_forward(ctx, spec, x5, dates, drop):
@@ -180,11 +202,11 @@ def wtae_forward(ctx, spec, x5, dates, drop):
     for i in range(n_stages - 1):
         red = down_conv_block(ctx, red, f"spatial_reduction.{i}", spec.encoder_norm, spec, valid, depthwise_separable=True)
     _, att = ltae(ctx, _unfold(red, B, T), dates, valid, "temporal_encoder", spec, drop, False)
-    fmaps = [E.temporal_aggregate(ctx, _unfold(f0, B, T), att, valid, spec.n_head)]
+    fmaps = [E.temporal_aggregate(ctx, _unfold(f0, B, T), att, valid, spec.n_head, spec.agg_mode)]
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
-    return _decoder_and_head(ctx, fmaps[-1], skips, spec), att
+    return _decoder_and_head(ctx, fmaps[-1], skips, spec, att)
 
 
 FORWARDS = {"utae": utae_forward, "timeunet": timeunet_forward, "wtae": wtae_forward}

@@ -173,18 +173,28 @@ class LTAE4WTAE(_Holder):
 
 
 class TemporalAggregator(_Holder):
-    """reference temporal_aggregator.py:6-12 (mode att_group is built)."""
+    """reference temporal_aggregator.py:6-12 (modes att_group, att_mean, mean)."""
 
     def __init__(self, mode="mean"):
         super().__init__()
-        if mode != "att_group":
-            raise NotImplementedError(f"agg_mode={mode!r}: crop2seg_amd builds 'att_group'")
+        if mode not in ("att_group", "att_mean", "mean"):
+            raise NotImplementedError(f"agg_mode={mode!r}: crop2seg_amd builds 'att_group', 'att_mean' and 'mean'")
         self.mode = mode
 
 
 # ------------------------------------------------------------------------------------------------
 # autograd bridge: one Function for the whole backbone (explicit tape inside)
 # ------------------------------------------------------------------------------------------------
+def _pack_outputs(out: "Fn.BackboneOutput"):
+    """Differentiable outputs of one forward in a fixed order: [head or last map, boundary head?, *maps?]."""
+    tensors = [out.logits if out.logits is not None else out.last]
+    if out.boundary is not None:
+        tensors.append(out.boundary)
+    if out.maps is not None:
+        tensors.extend(out.maps)
+    return tensors
+
+
 class _BackboneFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, dates, drop, names, *params):
@@ -193,16 +203,21 @@ class _BackboneFunction(torch.autograd.Function):
         tape = E.Tape()
         ectx = E.Ctx(p, dict(module.named_buffers()), grads, module._workspace(x.device), module.training, tape)
         with torch.no_grad():
-            logits, att = Fn.FORWARDS[module.spec.model](ectx, module.spec, x, dates, drop)
-        ctx.tape, ctx.ectx, ctx.names, ctx.logits = tape, ectx, names, logits
-        ctx.mark_non_differentiable(att)
-        return logits, att
+            out = Fn.FORWARDS[module.spec.model](ectx, module.spec, x, dates, drop)
+        diff = _pack_outputs(out)
+        # a map that is also returned as `last` (encoder=True) must be a distinct autograd output
+        ret = [diff[0]] + [t.view_as(t) if any(t is u for u in diff[:k + 1]) else t for k, t in enumerate(diff[1:])]
+        ctx.tape, ctx.ectx, ctx.names, ctx.diff = tape, ectx, names, diff
+        ctx.mark_non_differentiable(out.att)
+        return (out.att, *ret)
 
     @staticmethod
-    def backward(ctx, g_logits, _g_att):
+    def backward(ctx, _g_att, *g_outs):
         tape, ectx = ctx.tape, ctx.ectx
         with torch.no_grad():
-            tape.grads[ctx.logits.data_ptr()] = g_logits.contiguous().clone()
+            for t, g in zip(ctx.diff, g_outs):
+                if g is not None:
+                    tape.add_grad(t, g.contiguous().clone())
             tape.backward()
             out = []
             for n in ctx.names:
@@ -250,30 +265,42 @@ class _Backbone(nn.Module):
         named = [(n, p) for n, p in self.named_parameters()]
         names = [n for n, _ in named]
         params = [p for _, p in named]
+        spec = self.spec
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            logits, att = _BackboneFunction.apply(self, x, dates, drop, names, *params)
+            att, *diff = _BackboneFunction.apply(self, x, dates, drop, names, *params)
         else:
             with torch.no_grad():
                 ectx = E.Ctx(dict(named), dict(self.named_buffers()), None, self._workspace(x.device), self.training, None)
-                logits, att = Fn.FORWARDS[self.spec.model](ectx, self.spec, x, dates, drop)
-        if self.encoder or self.return_maps:
-            raise NotImplementedError("encoder / return_maps outputs are not built")
+                out = Fn.FORWARDS[spec.model](ectx, spec, x, dates, drop)
+                att, diff = out.att, _pack_outputs(out)
+        # tuple conventions of the reference (utae.py:233-252, wtae.py:259-279, timeunet.py:201-210)
+        head = diff[0]
+        boundary = diff[1] if spec.add_boundary_loss and not spec.encoder else None
+        n_lead = 1 + (1 if boundary is not None else 0)
+        maps = list(diff[n_lead:]) if (spec.return_maps or spec.encoder) else None
+        if spec.encoder:
+            return head, maps
+        lead = (head, boundary) if boundary is not None else (head,)
         if return_att:
-            return logits, att
-        return logits
+            return (*lead, att)
+        if spec.return_maps:
+            return (*lead, maps)
+        return lead if boundary is not None else head
 
 
 def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k, str_conv_s, str_conv_p,
                  agg_mode, encoder_norm, n_head, d_model, d_k, encoder, return_maps, pad_value, padding_mode, conv_type,
                  use_mbconv, add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss):
     unsupported = dict(use_mbconv=use_mbconv, add_squeeze_excit=add_squeeze_excit, use_abs_rel_enc=use_abs_rel_enc,
-                       use_doy=use_doy, add_linear=add_linear, add_boundary_loss=add_boundary_loss,
-                       encoder=encoder, return_maps=return_maps)
+                       use_doy=use_doy, add_linear=add_linear)
     bad = [k for k, v in unsupported.items() if v]
-    if bad or num_queries != 1 or conv_type != "2d" or agg_mode != "att_group":
+    if bad or num_queries != 1 or conv_type != "2d" or agg_mode not in ("att_group", "att_mean", "mean"):
         raise NotImplementedError(
-            "crop2seg_amd builds the reference's default backbone configuration (train.py:32-47,153-166); "
-            f"off-default options are not built: {bad or dict(num_queries=num_queries, conv_type=conv_type, agg_mode=agg_mode)}")
+            "crop2seg_amd builds the reference's default blocks (train.py:32-47,153-166) plus agg_mode in {att_group, att_mean, "
+            "mean}, add_boundary_loss, encoder and return_maps; not built: "
+            f"{bad or dict(num_queries=num_queries, conv_type=conv_type, agg_mode=agg_mode)}")
+    if encoder:
+        return_maps = True                      # utae.py:129-130
     if decoder_widths is None:
         decoder_widths = encoder_widths
     assert len(encoder_widths) == len(decoder_widths)
@@ -291,7 +318,10 @@ def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_con
                                 decoder_widths=list(decoder_widths), out_conv=list(out_conv), str_conv_k=str_conv_k,
                                 str_conv_s=str_conv_s, str_conv_p=str_conv_p, agg_mode=agg_mode,
                                 encoder_norm=encoder_norm, n_head=n_head, d_model=d_model, d_k=d_k,
-                                pad_value=float(pad_value), padding_mode=padding_mode)
+                                pad_value=float(pad_value), padding_mode=padding_mode,
+                                add_boundary_loss=bool(add_boundary_loss), encoder=bool(encoder),
+                                return_maps=bool(return_maps))
+    self.add_boundary_loss = bool(add_boundary_loss)
     return decoder_widths
 
 
@@ -331,6 +361,8 @@ class UTAE(_Backbone):
         self.temporal_encoder = LTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
         self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
+        if add_boundary_loss:                                           # utae.py:195-198
+            self.boundary_conv = ConvBlock([decoder_widths[0]] + [32, 2], padding_mode=padding_mode)
 
 
 class TimeUNet_v1(_Backbone):
@@ -345,9 +377,9 @@ class TimeUNet_v1(_Backbone):
         kwargs.pop("agg_mode", None)
         decoder_widths = _common_init(self, "timeunet", input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k,
                                       str_conv_s, str_conv_p, "att_group", encoder_norm, n_head, d_model, d_k, encoder,
-                                      return_maps, pad_value, padding_mode, conv_type, kwargs.get("use_mbconv", False),
+                                      return_maps, pad_value, padding_mode, conv_type, False,     # use_mbconv / add_boundary_loss:
                                       add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear,
-                                      kwargs.get("add_boundary_loss", False))
+                                      False)                                                     # swallowed by **kwargs in the reference
         self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
                                  norm=encoder_norm, padding_mode=padding_mode)
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
@@ -381,3 +413,5 @@ class WTAE(_Backbone):
         self.temporal_encoder = LTAE4WTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
         self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
+        if add_boundary_loss:                                           # wtae.py:215-218
+            self.boundary_conv = ConvBlock([decoder_widths[0]] + [32, 2], padding_mode=padding_mode)

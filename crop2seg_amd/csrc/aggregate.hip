@@ -14,6 +14,7 @@ struct Taps {
 __device__ __forceinline__ Taps taps_for(int dst, int in, int out) {
     Taps t;
     if (in == out) { t.i0 = dst; t.i1 = dst; t.w0 = 1.f; t.w1 = 0.f; return t; }
+    if (in == 1) { t.i0 = 0; t.i1 = 0; t.w0 = 1.f; t.w1 = 0.f; return t; }        // one weight per plane (mode "mean")
     const float scale = (float)in / (float)out;
     float src = scale * ((float)dst + 0.5f) - 0.5f;
     if (src < 0.f) src = 0.f;
@@ -132,6 +133,37 @@ __global__ __launch_bounds__(256) void agg_upsample_adjoint_kernel(const float* 
     }
 }
 
+// ---- agg_mode "att_mean" / "mean" (temporal_aggregator.py:46-56,71-77) reuse the kernels above with a derived weight tensor:
+//   att_mean: every channel group gets the head-averaged attention  v[g] = mean_h attn[h]   (g = 0..n_head-1)
+//   mean    : v[g][b][t] = valid[b,t] / #valid frames of b          (one weight per frame: a 1x1 "attention map")
+__global__ __launch_bounds__(256) void head_mean_kernel(const float* __restrict__ attn, float* __restrict__ v, int n_head, long n) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int h = 0; h < n_head; ++h) s += attn[(size_t)h * n + i];
+    s /= (float)n_head;
+    for (int h = 0; h < n_head; ++h) v[(size_t)h * n + i] = s;
+}
+__global__ __launch_bounds__(256) void head_mean_bwd_kernel(const float* __restrict__ gv, float* __restrict__ gattn, int n_head,
+                                                            long n, int accumulate) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int h = 0; h < n_head; ++h) s += gv[(size_t)h * n + i];
+    s /= (float)n_head;
+    for (int h = 0; h < n_head; ++h) gattn[(size_t)h * n + i] = accumulate ? gattn[(size_t)h * n + i] + s : s;
+}
+__global__ void frame_mean_weights_kernel(const int* __restrict__ valid, float* __restrict__ v, int n_head, int B, int T) {
+    const int b = blockIdx.x;
+    int cnt = 0;
+    for (int t = 0; t < T; ++t) cnt += (valid == nullptr || valid[b * T + t] != 0) ? 1 : 0;
+    const float w = 1.f / (float)cnt;
+    for (int e = threadIdx.x; e < n_head * T; e += blockDim.x) {
+        const int h = e / T, t = e % T;
+        v[((size_t)h * B + b) * T + t] = (valid == nullptr || valid[b * T + t] != 0) ? w : 0.f;
+    }
+}
+
 int check(const c2s_agg_desc* d) {
     C2S_REQUIRE(d && d->B > 0 && d->T > 0 && d->C > 0 && d->H > 0 && d->W > 0, "aggregate: bad shape");
     C2S_REQUIRE(d->n_head > 0 && d->C % d->n_head == 0, "aggregate: C %% n_head != 0");
@@ -143,6 +175,25 @@ int check(const c2s_agg_desc* d) {
 }
 
 }  // namespace
+
+extern "C" int c2s_attn_head_mean(const float* attn, float* v, int n_head, long n, void* stream) {
+    C2S_REQUIRE(attn && v && n_head > 0 && n > 0, "attn_head_mean: bad args");
+    hipLaunchKernelGGL(head_mean_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, attn, v, n_head, n);
+    C2S_CHECK_LAUNCH("attn_head_mean");
+    return C2S_OK;
+}
+extern "C" int c2s_attn_head_mean_bwd(const float* gv, float* gattn, int n_head, long n, int accumulate, void* stream) {
+    C2S_REQUIRE(gv && gattn && n_head > 0 && n > 0, "attn_head_mean_bwd: bad args");
+    hipLaunchKernelGGL(head_mean_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gv, gattn, n_head, n, accumulate);
+    C2S_CHECK_LAUNCH("attn_head_mean_bwd");
+    return C2S_OK;
+}
+extern "C" int c2s_frame_mean_weights(const int* valid, float* v, int n_head, int B, int T, void* stream) {
+    C2S_REQUIRE(v && n_head > 0 && B > 0 && T > 0, "frame_mean_weights: bad args");
+    hipLaunchKernelGGL(frame_mean_weights_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, valid, v, n_head, B, T);
+    C2S_CHECK_LAUNCH("frame_mean_weights");
+    return C2S_OK;
+}
 
 extern "C" int c2s_temporal_aggregate_fwd(const c2s_agg_desc* d, const float* x, const float* attn, const int* valid,
                                           float* out, void* stream) {

@@ -86,37 +86,57 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
     const int cpg = C / NH;
     const float* xq = p.x + (size_t)b * T * C * HW + pixq;     // + (t*C + c)*HW : float4 of 4 pixels
 
-    // ---- phase 1: GroupNorm statistics (padded frames included, tae.py:461); shifted sums, 4 partials per group
+    // ---- phase 1: GroupNorm statistics (padded frames included, tae.py:461): 4 partials per group, each a Chan merge of
+    // exact two-pass moments of the cpg values of one time step (error independent of the data, see the streaming kernel)
     {
         const int g = slot & 15, tq = slot >> 4;
-        const f32x4 K0 = *reinterpret_cast<const f32x4*>(xq + (size_t)(g * cpg) * HW);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 mean = zero, m2 = zero;
+        float cnt = 0.f;
+        const float nb = (float)cpg;
         for (int t = tq; t < T; t += 4) {
-#pragma unroll 8
-            for (int cc = 0; cc < cpg; ++cc) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(xq + (size_t)(t * C + g * cpg + cc) * HW) - K0;
-                s += d;
-                ss += d * d;
-            }
+            f32x4 v[16];                          // cpg <= 16 (check())
+            f32x4 sb = zero;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc)
+                if (cc < cpg) {
+                    v[cc] = *reinterpret_cast<const f32x4*>(xq + (size_t)(t * C + g * cpg + cc) * HW);
+                    sb += v[cc];
+                }
+            const f32x4 mb = sb / nb;
+            f32x4 qb = zero;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc)
+                if (cc < cpg) {
+                    const f32x4 d = v[cc] - mb;
+                    qb += d * d;
+                }
+            const float tot = cnt + nb;
+            const f32x4 delta = mb - mean;
+            mean += delta * (nb / tot);
+            m2 += qb + delta * delta * (cnt * nb / tot);
+            cnt = tot;
         }
-        // scratch [g][tq][2][16]
-        *reinterpret_cast<f32x4*>(Zl + ((g * 4 + tq) * 2 + 0) * 16 + 4 * q) = s;
-        *reinterpret_cast<f32x4*>(Zl + ((g * 4 + tq) * 2 + 1) * 16 + 4 * q) = ss;
+        // scratch [g][tq][2][16] (mean, M2); the count of partial tq is a function of T
+        *reinterpret_cast<f32x4*>(Zl + ((g * 4 + tq) * 2 + 0) * 16 + 4 * q) = mean;
+        *reinterpret_cast<f32x4*>(Zl + ((g * 4 + tq) * 2 + 1) * 16 + 4 * q) = m2;
     }
     __syncthreads();
     {
         const int g = hh;       // (pixel, group)
-        float s = 0.f, ss = 0.f;
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {
-            s += Zl[((g * 4 + tq) * 2 + 0) * 16 + px];
-            ss += Zl[((g * 4 + tq) * 2 + 1) * 16 + px];
+            const float nb = (float)(((T - tq + 3) / 4) * cpg);       // time steps tq, tq+4, ... < T
+            if (nb > 0.f) {
+                const float mb = Zl[((g * 4 + tq) * 2 + 0) * 16 + px], qb = Zl[((g * 4 + tq) * 2 + 1) * 16 + px];
+                const float tot = cnt + nb, delta = mb - mean;
+                mean = fmaf(delta, nb / tot, mean);
+                m2 += qb + delta * delta * (cnt * nb / tot);
+                cnt = tot;
+            }
         }
-        const float K0 = p.x[(size_t)b * T * C * HW + (size_t)(g * cpg) * HW + pix];
-        const float inv_n = 1.f / (float)(cpg * T);
-        const float md = s * inv_n;
-        const float mean = K0 + md;
-        const float var = fmaxf(ss * inv_n - md * md, 0.f);
+        const float var = fmaxf(m2 / cnt, 0.f);
         const float rstd = rsqrtf(var + p.eps);
         if (act) {
             p.stats[(pidx * NH + g) * 2] = mean;
@@ -940,11 +960,14 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     const float* xb = p.x + (size_t)b * T * C * HW + pix;          // + (t*C + c)*HW
 
     LT_STAMP(0);
-    // ---- P1: GroupNorm statistics of group w (padded frames included, tae.py:461); shifted sums
+    // ---- P1: GroupNorm statistics of group w (padded frames included, tae.py:461).
+    // Exact two-pass moments of every register batch (8 time steps x CPG channels), batches merged with Chan's update
+    // (n, mean, M2): the error does not depend on the data.  (A one-pass sum of squares shifted by the first sample lost
+    // 1e-5 of the variance wherever that sample sat 4 sigma from the group mean -- with half of the frames zero padding
+    // that showed up as 4e-5 on the attention weights.)
     {
         const float* xg = xb + (size_t)(w * CPG) * HW;
-        const float K0 = xg[0];
-        float s = 0.f, ss = 0.f;
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
         // 8 time steps x CPG channels per batch: 32 independent 256-byte loads in flight per wave
         for (int t0 = 0; t0 < T; t0 += 8) {
             float v[8][CPG];
@@ -954,22 +977,32 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
 #pragma unroll
                 for (int cc = 0; cc < CPG; ++cc) v[u][cc] = xg[(size_t)(t * C + cc) * HW];
             }
+            const int nt = T - t0 < 8 ? T - t0 : 8;
+            const float nb = (float)(nt * CPG);
+            float sb = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (t0 + u < T) {
+            for (int u = 0; u < 8; ++u)
+                if (u < nt) {
+#pragma unroll
+                    for (int cc = 0; cc < CPG; ++cc) sb += v[u][cc];
+                }
+            const float mb = sb / nb;
+            float qb = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nt) {
 #pragma unroll
                     for (int cc = 0; cc < CPG; ++cc) {
-                        const float d = v[u][cc] - K0;
-                        s += d;
-                        ss = fmaf(d, d, ss);
+                        const float d = v[u][cc] - mb;
+                        qb = fmaf(d, d, qb);
                     }
                 }
-            }
+            const float tot = cnt + nb, delta = mb - mean;
+            mean = fmaf(delta, nb / tot, mean);
+            m2 += qb + delta * delta * (cnt * nb / tot);
+            cnt = tot;
         }
-        const float inv_n = 1.f / (float)(CPG * T);
-        const float md = s * inv_n;
-        const float mean = K0 + md;
-        const float var = fmaxf(ss * inv_n - md * md, 0.f);
+        const float var = fmaxf(m2 / cnt, 0.f);
         const float rstd = rsqrtf(var + p.eps);
         if (act) {
             p.stats[(pidx * NH + w) * 2] = mean;

@@ -15,7 +15,7 @@ void c2s_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int c2s_abi_version(void) { return 1; }
+extern "C" int c2s_abi_version(void) { return 2; }
 extern "C" const char* c2s_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- per-device one-time set-up
@@ -370,23 +370,36 @@ __global__ __launch_bounds__(64) void dw_wgrad_reduce_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- cross entropy (train.py:463-468)
-// per block partial (sum w*nll, sum w) -> ws[2*blocks]; finalize -> ws_tot[2]; grad kernel uses ws_tot[1]
+// nn.CrossEntropyLoss(weight=w, label_smoothing=eps), reduction "mean" (torch semantics with class weights):
+//   loss_i = (1-eps) w[y_i] (-log p_i[y_i]) + (eps/K) sum_k w[k] (-log p_i[k]);  loss = sum_i loss_i / sum_i w[y_i]
+// Pixels whose target equals ignore_index (torch default -100) contribute to neither sum.  A target outside [0,K) that is
+// not ignore_index makes torch raise (device assert); here it is treated like ignore_index -- no out-of-bounds read.
+// per block partial (sum loss_i, sum w) -> ws[2*blocks]; finalize -> ws_tot[2]; grad kernel uses ws_tot[1]
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                      const float* __restrict__ cw, float* __restrict__ part, int B, int K,
-                                                     int HW) {
+                                                     int HW, float eps, long long ignore_index) {
     __shared__ float red[4][2];
     const long total = (long)B * HW;
     float num = 0.f, den = 0.f;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long long yy = target[e];
+        if (yy == ignore_index || yy < 0 || yy >= K) continue;
+        const int y = (int)yy;
         const int pix = (int)(e % HW), b = (int)(e / HW);
         const float* lp = logits + (size_t)b * K * HW + pix;
         float mx = lp[0];
         for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[(size_t)k * HW]);
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += __expf(lp[(size_t)k * HW] - mx);
-        const int y = (int)target[e];
         const float w = cw[y];
-        num += w * (mx + __logf(s) - lp[(size_t)y * HW]);
+        const float lse = mx + __logf(s);
+        float li = w * (lse - lp[(size_t)y * HW]);
+        if (eps > 0.f) {
+            float sm = 0.f;
+            for (int k = 0; k < K; ++k) sm += cw[k] * (lse - lp[(size_t)k * HW]);
+            li = (1.f - eps) * li + (eps / (float)K) * sm;
+        }
+        num += li;
         den += w;
     }
     num = wave_sum(num); den = wave_sum(den);
@@ -409,21 +422,39 @@ __global__ void ce_finalize_kernel(const float* __restrict__ part, float* __rest
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                      const float* __restrict__ cw, const float* __restrict__ tot,
-                                                     float* __restrict__ glogits, int B, int K, int HW) {
+                                                     float* __restrict__ glogits, int B, int K, int HW, float eps,
+                                                     long long ignore_index) {
     const long total = (long)B * HW;
     const float inv_den = 1.f / tot[1];
+    float wsum = 0.f;
+    if (eps > 0.f)
+        for (int k = 0; k < K; ++k) wsum += cw[k];
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int pix = (int)(e % HW), b = (int)(e / HW);
         const float* lp = logits + (size_t)b * K * HW + pix;
         float* gp = glogits + (size_t)b * K * HW + pix;
+        const long long yy = target[e];
+        if (yy == ignore_index || yy < 0 || yy >= K) {
+            for (int k = 0; k < K; ++k) gp[(size_t)k * HW] = 0.f;
+            continue;
+        }
+        const int y = (int)yy;
         float mx = lp[0];
         for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[(size_t)k * HW]);
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += __expf(lp[(size_t)k * HW] - mx);
-        const int y = (int)target[e];
         const float w = cw[y] * inv_den, inv_s = 1.f / s;
-        for (int k = 0; k < K; ++k)
-            gp[(size_t)k * HW] = w * (__expf(lp[(size_t)k * HW] - mx) * inv_s - (k == y ? 1.f : 0.f));
+        if (eps > 0.f) {
+            // (1-eps) w_y (p_k - delta_ky) + (eps/K) (W p_k - w_k), all over sum_i w[y_i]
+            const float a = (1.f - eps) * w, c = eps / (float)K * inv_den;
+            for (int k = 0; k < K; ++k) {
+                const float pk = __expf(lp[(size_t)k * HW] - mx) * inv_s;
+                gp[(size_t)k * HW] = a * (pk - (k == y ? 1.f : 0.f)) + c * (wsum * pk - cw[k]);
+            }
+        } else {
+            for (int k = 0; k < K; ++k)
+                gp[(size_t)k * HW] = w * (__expf(lp[(size_t)k * HW] - mx) * inv_s - (k == y ? 1.f : 0.f));
+        }
     }
 }
 
@@ -544,18 +575,22 @@ extern "C" size_t c2s_cross_entropy_workspace_floats(int B, int HW) {
 }
 
 extern "C" int c2s_cross_entropy(const float* logits, const int64_t* target, const float* class_w, float* loss,
-                                 float* glogits, int B, int K, int HW, float* workspace, size_t ws_floats, void* stream) {
+                                 float* glogits, int B, int K, int HW, float label_smoothing, long long ignore_index,
+                                 float* workspace, size_t ws_floats, void* stream) {
     C2S_REQUIRE(logits && target && class_w && loss && workspace, "cross_entropy: null pointer");
     C2S_REQUIRE(ws_floats >= 2 * CE_BLOCKS + 2 && B > 0 && K > 0 && HW > 0, "cross_entropy: bad args");
+    C2S_REQUIRE(label_smoothing >= 0.f && label_smoothing <= 1.f, "cross_entropy: label_smoothing must be in [0, 1]");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = grid_for((long)B * HW, CE_BLOCKS);
     float* tot = workspace + 2 * CE_BLOCKS;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, workspace, B, K, HW);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, workspace, B, K, HW,
+                       label_smoothing, ignore_index);
     C2S_CHECK_LAUNCH("ce_fwd");
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks);
     C2S_CHECK_LAUNCH("ce_finalize");
     if (glogits != nullptr) {
-        hipLaunchKernelGGL(ce_bwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, tot, glogits, B, K, HW);
+        hipLaunchKernelGGL(ce_bwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, tot, glogits, B, K, HW,
+                           label_smoothing, ignore_index);
         C2S_CHECK_LAUNCH("ce_bwd");
     }
     return C2S_OK;

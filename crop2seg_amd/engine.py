@@ -615,9 +615,21 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
 # =================================================================================================
 # temporal aggregation
 # =================================================================================================
-def temporal_aggregate(ctx: Ctx, x5: Tensor, attn: Tensor, valid: Optional[Tensor], n_head: int) -> Tensor:
-    """TemporalAggregator, mode att_group (reference temporal_aggregator.py:14-45,58-70)."""
+def temporal_aggregate(ctx: Ctx, x5: Tensor, attn: Tensor, valid: Optional[Tensor], n_head: int,
+                       mode: str = "att_group") -> Tensor:
+    """TemporalAggregator (reference temporal_aggregator.py:14-77).  att_group: head g weights channel group g;
+    att_mean: the head-averaged attention weights every channel; mean: plain mean over the valid frames.  The two
+    off-default modes run the same kernels on a derived weight tensor (c2s_attn_head_mean / c2s_frame_mean_weights)."""
     B, T, Cc, H, W = x5.shape
+    src_attn = attn
+    if mode == "att_mean":
+        attn = torch.empty_like(src_attn)
+        check(lib().c2s_attn_head_mean(src_attn.data_ptr(), attn.data_ptr(), n_head, src_attn[0].numel(), _stream()), "attn_head_mean")
+    elif mode == "mean":
+        attn = torch.empty(n_head, B, T, 1, 1, device=x5.device, dtype=torch.float32)
+        check(lib().c2s_frame_mean_weights(_ptr(valid), attn.data_ptr(), n_head, B, T, _stream()), "frame_mean_weights")
+    elif mode != "att_group":
+        raise ValueError(f"agg_mode {mode!r}")
     h, w = attn.shape[-2:]
     d = AggDesc(B, T, Cc, H, W, n_head, h, w)
     out = torch.empty(B, Cc, H, W, device=x5.device, dtype=torch.float32)
@@ -634,15 +646,25 @@ def temporal_aggregate(ctx: Ctx, x5: Tensor, attn: Tensor, valid: Optional[Tenso
             return
         existing = tape.grad_of(x5)
         gx = existing if existing is not None else torch.empty_like(x5)
-        gattn = tape.grad_of(attn)
-        if gattn is None:
-            gattn = torch.zeros_like(attn)
-            tape.grads[attn.data_ptr()] = gattn
+        if mode == "att_group":
+            gattn = tape.grad_of(attn)
+            if gattn is None:
+                gattn = torch.zeros_like(attn)
+                tape.grads[attn.data_ptr()] = gattn
+        else:
+            gattn = torch.zeros_like(attn)          # gradient of the derived weights
         nws = lib().c2s_temporal_aggregate_bwd_workspace_floats(C.byref(d))
         ws = ctx.ws.get("agg", nws)
         check(lib().c2s_temporal_aggregate_bwd(C.byref(d), x5.data_ptr(), attn.data_ptr(), _ptr(valid), g.data_ptr(),
                                                gx.data_ptr(), 1 if existing is not None else 0, gattn.data_ptr(),
                                                ws.data_ptr(), ws.numel(), _stream()), "temporal_aggregate_bwd")
+        if mode == "att_mean":
+            cur = tape.grad_of(src_attn)
+            tgt = cur if cur is not None else torch.empty_like(src_attn)
+            check(lib().c2s_attn_head_mean_bwd(gattn.data_ptr(), tgt.data_ptr(), n_head, src_attn[0].numel(),
+                                               1 if cur is not None else 0, _stream()), "attn_head_mean_bwd")
+            if cur is None:
+                tape.grads[src_attn.data_ptr()] = tgt
         if existing is None:
             tape.grads[x5.data_ptr()] = gx
 
@@ -807,9 +829,10 @@ def pixel_group_norm(ctx: Ctx, x: Tensor, prefix: str, groups: int) -> Tensor:
 # =================================================================================================
 # loss / optimiser
 # =================================================================================================
-def cross_entropy(logits: Tensor, target: Tensor, class_w: Tensor, ws: Workspace,
-                  want_grad: bool) -> Tuple[Tensor, Optional[Tensor]]:
-    """nn.CrossEntropyLoss(weight=class_w) (reference train.py:463-468).  Returns (loss[1], dlogits | None)."""
+def cross_entropy(logits: Tensor, target: Tensor, class_w: Tensor, ws: Workspace, want_grad: bool,
+                  label_smoothing: float = 0.0, ignore_index: int = -100) -> Tuple[Tensor, Optional[Tensor]]:
+    """nn.CrossEntropyLoss(weight=class_w, label_smoothing=...) (reference train.py:463-468; ignore_index is torch's
+    default -100: the reference ignores its last class through a zero class weight).  Returns (loss[1], dlogits | None)."""
     B, K = logits.shape[:2]
     HW = logits[0, 0].numel()
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
@@ -817,7 +840,8 @@ def cross_entropy(logits: Tensor, target: Tensor, class_w: Tensor, ws: Workspace
     n = lib().c2s_cross_entropy_workspace_floats(B, HW)
     w = ws.get("ce", n)
     check(lib().c2s_cross_entropy(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), loss.data_ptr(), _ptr(gl), B,
-                                  K, HW, w.data_ptr(), w.numel(), _stream()), "cross_entropy")
+                                  K, HW, float(label_smoothing), int(ignore_index), w.data_ptr(), w.numel(), _stream()),
+          "cross_entropy")
     return loss, gl
 
 

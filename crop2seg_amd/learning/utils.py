@@ -81,8 +81,13 @@ class TrainStep:
 
     def __init__(self, model, num_classes: int = 15, ignore_index: int = -1, lr: float = 1e-3,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, process_group=None,
-                 distributed: bool = False):
+                 distributed: bool = False, label_smoothing: float = 0.0, boundary_gamma: float = 2.0):
         self.model = model
+        self.label_smoothing = float(label_smoothing)       # train.py:172,466-468
+        self.boundary_gamma = float(boundary_gamma)         # FocalCELoss(gamma=2.0), src/learning/utils.py:259
+        self.num_classes = num_classes
+        if model.spec.encoder:
+            raise ValueError("TrainStep needs a model with a classification head (encoder=False)")
         self.lr, self.betas, self.eps = lr, betas, eps
         named = list(model.named_parameters())
         self.names = [n for n, _ in named]
@@ -124,9 +129,17 @@ class TrainStep:
         model = self.model
         tape = E.Tape()
         ctx = E.Ctx(self.params, dict(model.named_buffers()), self.grads, self.ws, model.training, tape)
-        logits, _att = Fn.FORWARDS[model.spec.model](ctx, model.spec, x, dates, drop)
-        loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True)
+        out = Fn.FORWARDS[model.spec.model](ctx, model.spec, x, dates, drop)
+        logits = out.logits
+        loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True, label_smoothing=self.label_smoothing)
         tape.grads[logits.data_ptr()] = glogits
+        if out.boundary is not None:
+            # src/learning/utils.py:283-285,318-324: y_b from the dilated one-hot labels, loss = CE + FocalCE(out_b, y_b)
+            from .losses import boundary_target, focal_ce
+            y_b = boundary_target(y)
+            _, g_b = focal_ce(out.boundary, y_b, self.boundary_gamma, want_grad=True, ws=self.ws, loss_out=loss)
+            tape.grads[out.boundary.data_ptr()] = g_b
+            self.last_boundary = out.boundary
         tape.backward()
         if not torch.cuda.is_current_stream_capturing():
             self.ws.finalize_pack_plan()                 # from the second step on, all weight packs are one launch

@@ -318,6 +318,13 @@ typedef struct c2s_agg_desc {
     int n_head, h, w;     /* attention maps [n_head,B,T,h,w] */
 } c2s_agg_desc;
 
+/* agg_mode "att_mean" / "mean" (temporal_aggregator.py:46-56,71-77) run the same kernels on a derived weight tensor:
+ *   c2s_attn_head_mean     : v[g][i] = mean_h attn[h][i] for every g < n_head (n = B*T*h*w entries per head)
+ *   c2s_attn_head_mean_bwd : gattn[h][i] (+)= (1/n_head) sum_g gv[g][i]
+ *   c2s_frame_mean_weights : v[g][b][t] = valid[b,t] / #valid frames of b   (a 1x1 "attention map" per frame; valid may be NULL) */
+int c2s_attn_head_mean(const float* attn, float* v, int n_head, long n, void* stream);
+int c2s_attn_head_mean_bwd(const float* gv, float* gattn, int n_head, long n, int accumulate, void* stream);
+int c2s_frame_mean_weights(const int* valid, float* v, int n_head, int B, int T, void* stream);
 int c2s_temporal_aggregate_fwd(const c2s_agg_desc* d, const float* x, const float* attn, const int* valid,
                                float* out, void* stream);
 size_t c2s_temporal_aggregate_bwd_workspace_floats(const c2s_agg_desc* d);
@@ -327,17 +334,69 @@ int c2s_temporal_aggregate_bwd(const c2s_agg_desc* d, const float* x, const floa
 
 /* ------------------------------------------------------------------------------------------------
  * Loss + optimiser of the train step (train.py:454,463-468; src/learning/utils.py:314-328).
- *   c2s_cross_entropy: weighted-mean CE with class weights w[K]; writes loss (1 float) and, if glogits
- *   != NULL, dL/dlogits.  workspace 2*blocks floats (see query).
+ *   c2s_cross_entropy: nn.CrossEntropyLoss(weight=w, label_smoothing=eps) (train.py:463-468), reduction "mean":
+ *   loss = sum_i [(1-eps) w[y_i] nll_i + (eps/K) sum_k w[k] (-log p_ik)] / sum_i w[y_i] over the pixels whose target is not
+ *   ignore_index (torch's default -100; targets outside [0,K) are skipped the same way -- torch raises instead); writes
+ *   loss (1 float) and, if glogits != NULL, dL/dlogits.  workspace 2*blocks floats (see query).
  *   c2s_adam_flat: torch.optim.Adam defaults on a flat parameter buffer.
  * ------------------------------------------------------------------------------------------------ */
 size_t c2s_cross_entropy_workspace_floats(int B, int HW);
 int c2s_cross_entropy(const float* logits, const int64_t* target, const float* class_w, float* loss,
-                      float* glogits, int B, int K, int HW, float* workspace, size_t ws_floats, void* stream);
+                      float* glogits, int B, int K, int HW, float label_smoothing, long long ignore_index,
+                      float* workspace, size_t ws_floats, void* stream);
 /* step_dev: optional DEVICE int holding the 1-based step count (takes precedence over `step`; lets a captured
  * hipGraph advance the bias correction on replay) */
 int c2s_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   int step, const int* step_dev, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Metrics tail of iterate() (src/learning/utils.py:332-336,377-380; src/learning/miou.py:55-117).
+ *   c2s_metrics_update: one pass over logits [B,K,HW] and target int64 [B,HW]:
+ *       pred      = argmax_k logits (first maximum, = torch.argmax)
+ *       second    = the largest of the remaining classes, lowest index on ties (torch.topk leaves tie order unspecified)
+ *       pred_top2 = (target == second) ? second : pred                                   (utils.py:377)
+ *       conf[t*K + pred] += 1 ; conf_top2[t*K + pred_top2] += 1   for targets in [0,K)   (miou.py:98-114, rows = target)
+ *     conf / conf_top2 are int64 [K,K] DEVICE accumulators (never reset by the call); conf_top2, pred, pred_top2 may be
+ *     NULL.  Integer atomics only: bit-exact and order independent.  K <= 32.
+ *   c2s_loss_meter_add: acc[0] += *loss, acc[1] += 1 (double[2], device): tnt AverageValueMeter.add(loss.item())
+ *     (utils.py:380) without the per-step host synchronisation.
+ * Boundary-loss pieces (N4; utils.py:198-222,283-285; focal_loss.py:7-44):
+ *   c2s_boundary_target: y_b = (get_dilated(y, K, connectivity 4).sum(1) > 1): 1 where a 4-neighbour holds another class.
+ *   c2s_focal_ce: FocalCELoss(gamma, size_average=True, weight=None): mean over targets != ignore_index of
+ *     -(1-pt)^gamma log pt; accumulate_loss != 0 adds it to *loss (utils.py:324 loss = loss + loss_b).
+ * ------------------------------------------------------------------------------------------------ */
+int c2s_metrics_update(const float* logits, const long long* target, long long* conf, long long* conf_top2,
+                       long long* pred, long long* pred_top2, int B, int K, int HW, void* stream);
+/* ConfusionMatrix.add for class-index predictions [n] (miou.py:98-114); pairs outside [0,K) are skipped */
+int c2s_confusion_add(const long long* pred, const long long* target, long long* conf, long n, int K, void* stream);
+int c2s_loss_meter_add(const float* loss, double* acc, void* stream);
+int c2s_boundary_target(const long long* y, long long* y_b, int B, int H, int W, void* stream);
+size_t c2s_focal_ce_workspace_floats(void);
+int c2s_focal_ce(const float* logits, const long long* target, float* loss, float* glogits, int B, int K, int HW,
+                 float gamma, long long ignore_index, int accumulate_loss, float* workspace, size_t ws_floats,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch movers on either side of the path.
+ *   c2s_collate_series: dataset tail + pad_collate in one pass (s2_ts_cz_crop.py:366-374,393-398; src/utils.py:14-32;
+ *     train.py:291).  src = the B series of a batch back to back, [sum_b T_b][Cs][HW] in the storage type of the .npy
+ *     files (host-pinned or device memory); offsets int64 [B+1] and src_dates int64 [sum_b T_b] must be device-accessible.
+ *     x[b,t,c] = (float(src[b][t][order[c]]) - mean[c]) / std[c] for t < T_b (IEEE fp32 subtract and divide, as torch),
+ *     pad_value frames for t >= T_b; dates[b,t] = src_dates or 0; valid[b*T+t] = (t < T_b).  mean / std (host arrays, in
+ *     OUTPUT channel order like the reference's norm_values) may both be NULL: no normalisation.
+ *   c2s_softmax_stitch: prediction.py:310-333: Softmax(dim=1), top-1 class (first maximum of the probabilities), tiling
+ *     '(h w) c h1 w1 -> c (h h1) (w w1)' with grid_w patches per row and the crop to out_h x out_w, for the `npatch`
+ *     patches starting at index first_patch: proba [K,out_h,out_w] f32, top1 [out_h,out_w] int64 (may be NULL).
+ * ------------------------------------------------------------------------------------------------ */
+#define C2S_SRC_F32 0
+#define C2S_SRC_I16 1
+#define C2S_SRC_U16 2
+int c2s_collate_series(const void* src, int src_dtype, const long long* offsets, const long long* src_dates, float* x,
+                       long long* dates, int* valid, int B, int T, int C, int Cs, int HW,
+                       const int* host_channel_order, const float* host_mean, const float* host_std, float pad_value,
+                       void* stream);
+int c2s_softmax_stitch(const float* logits, float* proba, long long* top1, int first_patch, int npatch, int K, int ph,
+                       int pw, int grid_w, int out_h, int out_w, void* stream);
 
 /* elementwise helpers */
 int c2s_fill(float* p, long n, float v, void* stream);

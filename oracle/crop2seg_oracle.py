@@ -58,6 +58,8 @@ class BackboneConfig:
     d_k: int = 4
     pad_value: Optional[float] = 0.0
     padding_mode: str = "reflect"
+    add_boundary_loss: bool = False          # second head boundary_conv = ConvBlock([dec0, 32, 2]) (utae.py:195-198)
+    boundary_gamma: float = 2.0              # FocalCELoss(gamma=2.0) (src/learning/utils.py:259)
     pe_period: float = 1000.0                # PositionalEncoder T (positional_encoding.py:11)
     attn_dropout: float = 0.1                # tae.py:816
     mlp_dropout: float = 0.2                 # tae.py:361
@@ -331,7 +333,14 @@ def _decoder_and_head(out: Tensor, skips: List[Tensor], sd: State, cfg: Backbone
     for i in range(n_stages - 1):
         out = up_conv_block(out, skips[i], sd, f"up_blocks.{i}", cfg, training, bn)
     # out_conv = ConvBlock([dec0]+out_conv), BatchNorm + ReLU after BOTH convs (utae.py:191; conv.py:184)
-    return conv_layer(out, sd, "out_conv.conv", len(cfg.out_conv), "batch", 3, 1, 1, cfg, training, bn)
+    logits = conv_layer(out, sd, "out_conv.conv", len(cfg.out_conv), "batch", 3, 1, 1, cfg, training, bn)
+    if cfg.add_boundary_loss:                # utae.py:236-238: out_ = out_conv(out); out_b = boundary_conv(out)
+        LAST_BOUNDARY.clear()
+        LAST_BOUNDARY.append(conv_layer(out, sd, "boundary_conv.conv", 2, "batch", 3, 1, 1, cfg, training, bn))
+    return logits
+
+
+LAST_BOUNDARY: List[Tensor] = []             # boundary-head logits of the most recent forward (add_boundary_loss)
 
 
 def utae_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, training: bool = False,
@@ -428,8 +437,13 @@ def loss_and_grads(sd: State, x: Tensor, dates: Tensor, y: Tensor, cfg: Backbone
     names = parameter_names(sd)
     work = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
     bn = BNState()
+    label_smoothing = kw.pop("label_smoothing", 0.0)
     logits, _ = forward(work, x, dates, cfg, training=training, bn=bn, **kw)
-    loss = cross_entropy(logits, y, cfg.out_conv[-1])
+    loss = cross_entropy(logits, y, cfg.out_conv[-1], label_smoothing=label_smoothing)
+    if cfg.add_boundary_loss:                # src/learning/utils.py:283-285,318-324
+        from . import tail_oracle as TO
+        y_b = TO.boundary_target(y, cfg.out_conv[-1])
+        loss = loss + TO.focal_ce(LAST_BOUNDARY[0], y_b, cfg.boundary_gamma)
     gs = torch.autograd.grad(loss, [work[n] for n in names], allow_unused=True)
     grads = {n: (g if g is not None else torch.zeros_like(work[n])) for n, g in zip(names, gs)}
     return logits.detach(), loss.detach(), grads, bn

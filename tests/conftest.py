@@ -19,7 +19,9 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Whole-model fixtures (tests/golden/tail_*.npz belong to the metrics / loss tests)."""
+    names = (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(n for n in names if not n.startswith("tail_"))
 
 
 class Golden:
@@ -35,7 +37,8 @@ class Golden:
         self.sd = seeded.make_state(self.key_shapes, self.meta["wseed"], self.meta["flavour"])
         drift = (seeded.checksum(self.sd).numpy() - self.z["wsum"])
         assert np.abs(drift).max() < 1e-6 * max(1.0, np.abs(self.z["wsum"]).max()), "seeded weights drifted (torch RNG changed?)"
-        self.cfg = BackboneConfig(model=self.meta["model"])
+        self.ctor = self.meta.get("ctor") or {}          # off-default constructor kwargs (agg_mode, add_boundary_loss)
+        self.cfg = BackboneConfig(model=self.meta["model"], **self.ctor)
         if self.meta["widths"]:
             self.cfg.encoder_widths, self.cfg.decoder_widths = self.meta["widths"]
         self.x = torch.from_numpy(self.z["x"])

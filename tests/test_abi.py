@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/c2s_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes binding and header disagree"
-    assert _lib.lib().c2s_abi_version() == 1
+    assert _lib.lib().c2s_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():
@@ -95,7 +95,22 @@ def test_offdefault_flags_fail_loudly():
     with pytest.raises(NotImplementedError):
         C2S.UTAE(input_dim=10, use_mbconv=True)
     with pytest.raises(NotImplementedError):
-        C2S.WTAE(input_dim=10, agg_mode="mean")
+        C2S.WTAE(input_dim=10, agg_mode="max")
+    with pytest.raises(NotImplementedError):
+        C2S.UTAE(input_dim=10, num_queries=2)
+
+
+def test_optional_heads_extend_the_state_dict_like_the_reference():
+    """add_boundary_loss adds boundary_conv = ConvBlock([dec0, 32, 2]) after out_conv (utae.py:195-198, wtae.py:215-218);
+    TimeUNet_v1 swallows the flag through **kwargs (timeunet.py:19-45)."""
+    import crop2seg_amd as C2S
+    base = list(C2S.UTAE(input_dim=10, out_conv=[32, 15]).state_dict())
+    withb = list(C2S.UTAE(input_dim=10, out_conv=[32, 15], add_boundary_loss=True, agg_mode="att_mean").state_dict())
+    extra = withb[len(base):]
+    assert withb[:len(base)] == base and len(extra) == 14 and all(k.startswith("boundary_conv.conv.conv.") for k in extra)
+    assert len(C2S.WTAE(input_dim=10, add_boundary_loss=True, agg_mode="mean").state_dict()) == 185 + 14
+    assert len(C2S.TimeUNet_v1(input_dim=10, add_boundary_loss=True, use_mbconv=True).state_dict()) == 158
+    assert C2S.UTAE(input_dim=10, encoder=True).spec.return_maps
 
 
 def test_get_model_mapping():

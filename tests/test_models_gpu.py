@@ -17,7 +17,7 @@ def build(g):
     import crop2seg_amd as C2S
     from crop2seg_amd.backbones import functional as Fn
     cls = {"utae": C2S.UTAE, "timeunet": C2S.TimeUNet_v1, "wtae": C2S.WTAE}[g.cfg.model]
-    net = cls(input_dim=10, out_conv=[32, 15])
+    net = cls(input_dim=10, out_conv=[32, 15], **g.ctor)
     got = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     assert got == g.key_shapes, "state_dict layout differs from the reference"
     net.load_state_dict(g.sd)
@@ -61,7 +61,8 @@ def test_model_matches_reference(goldens, name, conv_mode):
         net.spec.attn_dropout = 0.0
         net.spec.mlp_dropout = 0.0
     x, dates, y = g.x.cuda(), g.dates.cuda(), g.y.cuda()
-    logits, att = net(x, batch_positions=dates, return_att=True, dropout_state=drop)
+    outs = net(x, batch_positions=dates, return_att=True, dropout_state=drop)
+    logits, att = outs[0], outs[-1]
     ref_logits = torch.from_numpy(g.z["logits"])
     ref_att = torch.from_numpy(g.z["att"])
     scale = float(ref_logits.abs().max())
@@ -74,6 +75,18 @@ def test_model_matches_reference(goldens, name, conv_mode):
     wgt = torch.ones(15, device="cuda")
     wgt[-1] = 0
     loss = torch.nn.functional.cross_entropy(logits, y, weight=wgt)
+    if g.ctor.get("add_boundary_loss"):
+        # boundary head (utae.py:236-238) + focal term of iterate() (src/learning/utils.py:283-285,318-324).  The drop-in
+        # path hands torch autograd the head's logits; the focal loss itself is evaluated with torch ops here (its HIP
+        # kernel is covered by tests/test_tail_gpu.py and by test_train_step_boundary_matches_oracle below)
+        from oracle import tail_oracle as TO
+        from crop2seg_amd.learning.losses import boundary_target
+        out_b = outs[1]
+        ref_b = torch.from_numpy(g.z["logits_b"])
+        assert float((out_b.detach().cpu() - ref_b).abs().max()) <= 1e-3 * float(ref_b.abs().max())
+        y_b = boundary_target(y)
+        assert torch.equal(y_b.cpu(), TO.boundary_target(g.y, 15))
+        loss = loss + TO.focal_ce(out_b, y_b, 2.0)
     assert abs(float(loss) - float(g.z["loss"])) <= 1e-3 * abs(float(g.z["loss"]))
     loss.backward()
     if conv_mode != "f32":
@@ -137,6 +150,62 @@ def test_train_step_matches_oracle(goldens):
         d_got = (got[n].detach().cpu() - g.sd[n])[mask]
         if d_ref.numel():
             assert float((d_ref - d_got).abs().max()) <= 2e-4, n
+
+
+@pytest.mark.parametrize("name,smoothing", [("utae_train_mean_boundary_tame", 0.0), ("utae_train_p0_tame", 0.1)])
+def test_train_step_boundary_and_smoothing_match_oracle(goldens, name, smoothing):
+    """TrainStep with the boundary head (CE + focal loss through the HIP loss kernels, both heads on the tape) and with
+    label smoothing (train.py:466-468) == the oracle's loss and gradients on the same batch."""
+    from oracle import crop2seg_oracle as O
+    from crop2seg_amd.learning.utils import TrainStep
+    g = goldens(name)
+    net, drop = build(g)
+    net.train()
+    net.spec.attn_dropout = 0.0
+    net.spec.mlp_dropout = 0.0
+    step = TrainStep(net, num_classes=15, label_smoothing=smoothing)
+    loss, logits = step(g.x.cuda(), g.dates.cuda(), g.y.cuda(), dropout_state=drop, apply_update=False)
+    _, ref_loss, grads, _ = O.loss_and_grads(g.sd, g.x, g.dates, g.y, g.cfg, True, label_smoothing=smoothing)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+    if smoothing == 0.0:
+        assert abs(float(loss) - float(g.z["loss"])) <= 1e-4 * abs(float(g.z["loss"]))       # the reference's own value
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in g.sd.items()}
+    _, _, g64, _ = O.loss_and_grads(sd64, g.x.double(), g.dates, g.y, g.cfg, True, label_smoothing=smoothing)
+    gmax = max(float(v.norm()) for v in g64.values())
+    for n, ref in g64.items():
+        got = step.grads[n].detach().double().cpu()
+        err, err32, sc = float((got - ref).norm()), float((grads[n].double() - ref).norm()), float(ref.norm())
+        assert err <= max(3 * err32, 1e-3 * sc) + 2e-5 * gmax, (n, err / max(sc, 1e-30), err32 / max(sc, 1e-30))
+
+
+def test_encoder_and_return_maps_outputs(goldens):
+    """encoder=True / return_maps=True tuple conventions (utae.py:224-252): maps = [L-TAE output, up-block outputs...];
+    the logits are unchanged by asking for the maps."""
+    import crop2seg_amd as C2S
+    g = goldens("utae_eval_nopad_tame")
+    x, dates = g.x.cuda(), g.dates.cuda()
+    plain = C2S.UTAE(input_dim=10, out_conv=[32, 15])
+    plain.load_state_dict(g.sd)
+    plain = plain.cuda().eval()
+    withmaps = C2S.UTAE(input_dim=10, out_conv=[32, 15], return_maps=True)
+    withmaps.load_state_dict(g.sd)
+    withmaps = withmaps.cuda().eval()
+    enc = C2S.UTAE(input_dim=10, out_conv=[32, 15], encoder=True)
+    enc.load_state_dict(g.sd)
+    enc = enc.cuda().eval()
+    with torch.no_grad():
+        logits = plain(x, batch_positions=dates)
+        l2, maps = withmaps(x, batch_positions=dates)
+        last, maps_e = enc(x, batch_positions=dates)
+    assert torch.equal(logits, l2) and len(maps) == 4 and len(maps_e) == 4
+    assert [tuple(m.shape[1:]) for m in maps] == [(128, 2, 2), (64, 4, 4), (32, 8, 8), (32, 16, 16)]
+    assert torch.equal(last, maps_e[-1]) and all(torch.equal(a, b) for a, b in zip(maps, maps_e))
+    # gradients flow through the maps on the drop-in path
+    enc.train()
+    last, maps_e = enc(x, batch_positions=dates)
+    (last.square().mean() + maps_e[1].mean()).backward()
+    assert float(enc.in_conv.conv.conv[0].weight.grad.abs().max()) > 0
+    assert enc.out_conv.conv.conv[0].weight.grad is None or float(enc.out_conv.conv.conv[0].weight.grad.abs().max()) == 0.0
 
 
 def test_full_size_properties():

@@ -258,9 +258,21 @@ def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     kd = keep.cuda() if drop else None
     e_out, a_out = E.ltae_attention(ctx, xd, dates.cuda(), valid.view(-1).cuda(), "te", 16, 4, 256, 1000.0,
                                     0.1 if drop else 0.0, with_emb, 0, kd)
-    assert float((a_out.cpu() - attn5).abs().max()) < 2e-6
+    # forward bar: 2e-6 absolute on the attention weights / 1e-5 relative on the embedding against the fp32 oracle, or -- where
+    # the fp32 oracle itself is further than that from an fp64 evaluation (T = 61 with half of the frames padded: larger
+    # normalised activations, sharper softmax) -- three times the oracle's own fp32 error (SURVEY.md 8c.4 criterion)
+    with torch.no_grad():
+        sd64 = {k: v.double() for k, v in sd.items()}
+        emb64, attn64 = O.ltae_attention(x.detach().double(), dates, ~valid.bool(), sd64, "te", cfg,
+                                         keep.double() if drop else None)
+    a64 = attn64.view(16, B, h, h, T).permute(0, 1, 4, 2, 3)
+    e64 = emb64.view(B, h, h, 256).permute(0, 3, 1, 2)
+    a_err32 = float((attn5.detach().double() - a64).abs().max())
+    assert float((a_out.cpu().double() - a64).abs().max()) <= max(3 * a_err32, 2e-6)
     if with_emb:
-        assert rel(e_out, emb4) < 1e-5
+        e_err32 = rel(emb4, e64)
+        assert rel(e_out, e64) <= max(3 * e_err32, 1e-5)
+    del sd64, emb64, attn64, a64, e64
     ctx.tape.grads[a_out.data_ptr()] = g_attn.cuda().contiguous()
     if with_emb:
         ctx.tape.grads[e_out.data_ptr()] = g_emb.cuda().contiguous()

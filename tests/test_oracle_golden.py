@@ -30,6 +30,12 @@ def test_oracle_matches_reference_forward(goldens, name):
             kw.pop("mlp_keep", None)
         logits, att = O.forward(g.sd, g.x, g.dates, g.cfg, training=g.training, bn=bn, **kw)
         loss = O.cross_entropy(logits, g.y, 15)
+        if g.cfg.add_boundary_loss:          # second head + focal term (utae.py:236-238; src/learning/utils.py:283-285,318-324)
+            from oracle import tail_oracle as TO
+            out_b = O.LAST_BOUNDARY[0]
+            ref_b = torch.from_numpy(g.z["logits_b"])
+            assert (out_b - ref_b).abs().max() <= 2e-5 * ref_b.abs().max()
+            loss = loss + TO.focal_ce(out_b, TO.boundary_target(g.y, 15), 2.0)
     ref_logits = torch.from_numpy(g.z["logits"])
     ref_att = torch.from_numpy(g.z["att"])
     scale = ref_logits.abs().max()

@@ -1,0 +1,175 @@
+"""GPU parity of the steps on either side of the backbone through the C ABI, against
+oracle/tail_oracle.py and the vectors of the imported reference (tests/golden/tail_*.npz).  Integer / index results are
+held to bit-exactness; the fp32 collate arithmetic too (IEEE subtract and divide); softmax / focal values to 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tail_oracle as TO  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["tail_miou_k15", "tail_miou_k4"])
+def test_metrics_kernel_matches_reference_fixture(name):
+    from crop2seg_amd.learning.metrics import IoU, StepMeters
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    K, ign = int(z["K"]), int(z["ignore_index"])
+    iou = IoU(K, ignore_index=ign)
+    iou_idx = IoU(K, ignore_index=ign)
+    meters = StepMeters(K, ignore_index=ign)
+    conf2 = np.zeros((K, K), dtype=np.int64)
+    for logits, y in zip(z["logits"], z["y"]):
+        lg, yy = torch.from_numpy(logits).cuda(), torch.from_numpy(y).cuda()
+        iou.add(lg, yy)                                          # (N,K,H,W) scores: arg-maxed inside the kernel
+        iou_idx.add(lg.argmax(dim=1), yy)                        # (N,H,W) class indices
+        pred, pred2 = meters.update(lg, yy, torch.tensor([1.5], device="cuda"), want_pred=True)
+        rp, rp2, _, rc2 = TO.metrics_tail(torch.from_numpy(logits), torch.from_numpy(y), K)
+        assert torch.equal(pred.cpu(), rp) and torch.equal(pred2.cpu(), rp2)
+        conf2 += rc2
+    for m in (iou, iou_idx, meters.iou):
+        assert np.array_equal(m.conf_metric.conf.cpu().numpy(), z["conf"])
+        miou, acc = m.get_miou_acc()
+        assert miou == float(z["miou"]) and acc == float(z["acc"])
+    assert np.array_equal(meters.iou_top2.conf_metric.conf.cpu().numpy(), conf2)
+    assert meters.get_miou_acc_top2() == TO.miou_acc(conf2, ign)
+    assert meters.loss_mean() == 1.5
+
+
+def test_metrics_at_full_size_properties():
+    """B=4, 128x128, K=15 (BASELINE configs[1] logits): row sums of the confusion matrix = class histogram of the target;
+    top-2 accuracy >= top-1 accuracy; >= 40 % exactly-zero logits resolve to the lowest class index."""
+    from crop2seg_amd.learning.metrics import StepMeters
+    g = torch.Generator().manual_seed(3)
+    logits = torch.relu(torch.randn(4, 15, 128, 128, generator=g)) * (torch.rand(4, 15, 128, 128, generator=g) > 0.45)
+    y = torch.randint(0, 15, (4, 128, 128), generator=g)
+    m = StepMeters(15, ignore_index=-1)
+    pred, pred2 = m.update(logits.cuda(), y.cuda(), want_pred=True)
+    conf = m.iou.conf_metric.conf.cpu().numpy()
+    assert np.array_equal(conf.sum(1), np.bincount(y.reshape(-1).numpy(), minlength=15))
+    assert np.array_equal(conf, TO.confusion_matrix(logits.argmax(1).numpy(), y.numpy(), 15))
+    assert torch.equal(pred.cpu(), logits.argmax(1))
+    c2 = m.iou_top2.conf_metric.conf.cpu().numpy()
+    assert np.trace(c2) >= np.trace(conf) and c2.sum() == conf.sum() == 4 * 128 * 128
+    allzero = (logits.abs().sum(1) == 0)
+    assert bool((pred.cpu()[allzero] == 0).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 17), (4, 128, 128), (1, 1, 5)])
+def test_boundary_target_bit_exact(shape):
+    from crop2seg_amd.learning.losses import boundary_target
+    g = torch.Generator().manual_seed(11)
+    # blobs of classes, like a crop map
+    y = torch.randint(0, 15, (shape[0], (shape[1] + 3) // 4, (shape[2] + 3) // 4), generator=g)
+    y = y.repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :shape[1], :shape[2]].contiguous()
+    assert torch.equal(boundary_target(y.cuda()).cpu(), TO.boundary_target(y, 15))
+
+
+@pytest.mark.parametrize("name", ["tail_focal_g2", "tail_focal_g1_ignore"])
+def test_focal_loss_matches_reference_fixture(name):
+    from crop2seg_amd.learning.losses import focal_ce
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    loss, grad = focal_ce(torch.from_numpy(z["logits"]).cuda(), torch.from_numpy(z["y"]).cuda(), float(z["gamma"]), want_grad=True)
+    assert abs(float(loss) - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+    ref = torch.from_numpy(z["grad"])
+    assert float((grad.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    base = torch.full((1,), 0.25, device="cuda")
+    focal_ce(torch.from_numpy(z["logits"]).cuda(), torch.from_numpy(z["y"]).cuda(), float(z["gamma"]), loss_out=base)
+    assert abs(float(base) - 0.25 - float(z["loss"])) <= 1e-5
+
+
+@pytest.mark.parametrize("eps,ignore", [(0.0, False), (0.1, False), (0.2, True)])
+def test_cross_entropy_label_smoothing_and_ignore(eps, ignore):
+    """nn.CrossEntropyLoss(weight, label_smoothing) with a zero class weight (train.py:463-468) and torch's ignore_index."""
+    from crop2seg_amd import engine as E
+    g = torch.Generator().manual_seed(29)
+    logits = (2 * torch.randn(3, 15, 32, 32, generator=g)).requires_grad_(True)
+    y = torch.randint(0, 15, (3, 32, 32), generator=g)
+    if ignore:
+        y[torch.rand(3, 32, 32, generator=g) < 0.1] = -100
+    cw = torch.ones(15)
+    cw[-1] = 0
+    ref = torch.nn.functional.cross_entropy(logits, y, weight=cw, label_smoothing=eps)
+    ref.backward()
+    loss, gl = E.cross_entropy(logits.detach().cuda(), y.cuda(), cw.cuda(), E.Workspace(torch.device("cuda")), True,
+                               label_smoothing=eps)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert float((gl.cpu() - logits.grad).norm() / logits.grad.norm()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16, np.float32])
+@pytest.mark.parametrize("mode", ["zero_copy", "staged"])
+def test_collate_series_bit_exact(dtype, mode):
+    from crop2seg_amd.utils import CHANNELS_LIKE_PASTIS, SeriesCollator
+    rng = np.random.default_rng(1)
+    lengths = [5, 3, 7, 1]
+    if dtype == np.float32:
+        series = [rng.normal(1500, 900, (t, 10, 32, 32)).astype(np.float32) for t in lengths]
+    else:
+        series = [rng.integers(0, 12000, (t, 10, 32, 32)).astype(dtype) for t in lengths]
+    dates = [np.sort(rng.integers(1, 400, t)).astype(np.int64) for t in lengths]
+    mean = rng.normal(1200, 300, 10)
+    std = rng.uniform(300, 900, 10)
+    coll = SeriesCollator(CHANNELS_LIKE_PASTIS, mean, std, mode=mode)
+    x, dd, valid = coll(series, dates)
+    rx, rd = TO.collate_series(series, dates, CHANNELS_LIKE_PASTIS, mean, std)
+    assert x.shape == rx.shape
+    assert torch.equal(x.cpu(), rx), "collate arithmetic must be bit-exact (IEEE fp32 subtract + divide)"
+    assert torch.equal(dd.cpu(), rd)
+    assert valid.view(4, 7).cpu().tolist() == [[1] * t + [0] * (7 - t) for t in lengths]
+    # the model's own frame detection agrees with the flags the collator emits
+    from crop2seg_amd import engine as E
+    assert torch.equal(E.frame_flags(x, 0.0), valid)
+    # second call reuses the pinned staging buffers; fixed T (pad_collate max_size); no normalisation
+    c2 = SeriesCollator(None, None, None, max_size=9, mode=mode)
+    x2, d2, v2 = c2(series[:2], dates[:2])
+    r2, _ = TO.collate_series(series[:2], dates[:2], list(range(10)), None, None)
+    assert x2.shape == (2, 9, 10, 32, 32) and torch.equal(x2[:, :5].cpu(), r2) and float(x2[:, 5:].abs().max()) == 0.0
+
+
+def test_softmax_stitch_matches_restatement():
+    from crop2seg_amd import engine as E
+    from crop2seg_amd._lib import check, lib
+    g = torch.Generator().manual_seed(13)
+    grid, h1, K, crop = 3, 16, 15, 41
+    logits = torch.relu(2 * torch.randn(grid * grid, K, h1, h1, generator=g)) * (torch.rand(grid * grid, K, h1, h1, generator=g) > 0.3)
+    rp, rt = TO.softmax_stitch([l[None] for l in logits], grid=grid, crop=crop)
+    proba = torch.full((K, crop, crop), -1.0, device="cuda")
+    top1 = torch.full((crop, crop), -1, device="cuda", dtype=torch.int64)
+    ld = logits.cuda()
+    for first, n in ((0, 4), (4, 5)):                             # two batches of patches
+        check(lib().c2s_softmax_stitch(ld[first:first + n].contiguous().data_ptr(), proba.data_ptr(), top1.data_ptr(), first, n, K,
+                                       h1, h1, grid, crop, crop, E._stream()), "softmax_stitch")
+    assert float((proba.cpu() - rp).abs().max()) <= 1e-6
+    agree = (top1.cpu() == rt)
+    # top-1 = first maximum of the probabilities; a disagreement needs two probabilities within one ulp of each other
+    top2 = rp.topk(2, dim=0).values
+    assert bool(agree[(top2[0] - top2[1]) > 1e-6].all()) and float(agree.float().mean()) > 0.99
+
+
+def test_predict_tile_equals_patch_by_patch():
+    """N3: batched tile inference == the reference's B=1 loop (same model, eval mode), bit for bit."""
+    import crop2seg_amd as C2S
+    from crop2seg_amd.inference import predict_tile
+    from oracle import seeded
+    net = C2S.UTAE(input_dim=10, out_conv=[32, 15])
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(seeded.make_state(ks, 3, "tame"))
+    net = net.cuda().eval()
+    grid, h1, T = 3, 32, 4
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(grid * grid, T, 10, h1, h1, generator=g).cuda()
+    dates = (5 * torch.arange(T))[None].repeat(grid * grid, 1).cuda()
+    proba, top1 = predict_tile(net, x, dates, grid=grid, crop=90, batch_size=4)
+    with torch.no_grad():
+        singles = [net(x[i:i + 1].contiguous(), batch_positions=dates[i:i + 1].contiguous()).cpu() for i in range(grid * grid)]
+    rp, rt = TO.softmax_stitch(singles, grid=grid, crop=90)
+    assert proba.shape == (15, 90, 90) and float((proba.cpu() - rp).abs().max()) <= 1e-6
+    top2 = rp.topk(2, dim=0).values
+    assert bool((top1.cpu() == rt)[(top2[0] - top2[1]) > 1e-6].all())
+    p1, t1 = predict_tile(net, x, dates, grid=grid, crop=90, batch_size=1)
+    assert torch.equal(p1, proba) and torch.equal(t1, top1), "batched inference must equal the B=1 loop bit for bit"
