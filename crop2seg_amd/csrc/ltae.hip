@@ -46,13 +46,37 @@ struct LtaeParams {
     const uint64_t* seed_dev;   // optional device-side step counter added to the seed (hipGraph replay)
 };
 
+// Attention dropout (tae.py:837).  Explicit keep mask [16,P,T] (tests) or a counter-based RNG: ONE 32-bit avalanche hash per
+// pair of time steps (2u, 2u+1) of a (head, pixel) row, 16 bits per element -- drop probability round(p * 2^16) / 2^16 with the
+// matching scale, so E[keep * scale] = 1 exactly.  (Two full hashes per element cost 4 quarter-rate v_mul_lo_u32 each:
+// 6.6k of the 12k cycles the dropout + store phase of a 16-pixel tile took.)
+struct DropCtx {
+    uint32_t key, thr;
+    float inv;
+    int half_t;
+};
+__device__ __forceinline__ DropCtx drop_ctx(const LtaeParams& p) {
+    DropCtx d;
+    const uint64_t seed = p.seed + (p.seed_dev != nullptr ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+    d.key = c2s_hash32((uint32_t)seed ^ c2s_hash32((uint32_t)(seed >> 32) + 0x9E3779B9u));
+    d.thr = (uint32_t)(p.drop_p * 65536.f + 0.5f);
+    d.inv = 65536.f / (65536.f - (float)d.thr);
+    d.half_t = (p.T + 1) >> 1;
+    return d;
+}
+__device__ __forceinline__ uint32_t drop_bits(const DropCtx& d, long row, int u) {
+    const uint64_t i2 = (uint64_t)row * (uint64_t)d.half_t + (uint64_t)u;
+    return c2s_hash32((uint32_t)i2 ^ d.key ^ (uint32_t)(i2 >> 32) * 0x85EBCA6Bu);
+}
+__device__ __forceinline__ float drop_pick(const DropCtx& d, uint32_t bits, int t) {
+    const uint32_t u16 = (t & 1) ? bits >> 16 : bits & 0xffffu;
+    return u16 >= d.thr ? d.inv : 0.f;
+}
 __device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_total, long pidx, int t) {
     if (p.drop_p <= 0.f) return 1.f;
-    const long idx = ((long)h * P_total + pidx) * p.T + t;
-    const float inv = 1.f / (1.f - p.drop_p);
-    if (p.keep != nullptr) return p.keep[idx] != 0.f ? inv : 0.f;
-    const uint64_t seed = p.seed + (p.seed_dev != nullptr ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
-    return c2s_uniform(seed, (uint64_t)idx) >= p.drop_p ? inv : 0.f;
+    if (p.keep != nullptr) return p.keep[((long)h * P_total + pidx) * p.T + t] != 0.f ? 1.f / (1.f - p.drop_p) : 0.f;
+    const DropCtx d = drop_ctx(p);
+    return drop_pick(d, drop_bits(d, (long)h * P_total + pidx, t >> 1), t);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -1200,6 +1224,383 @@ __global__ __launch_bounds__(1024) void ltae_stream_fwd_kernel(LtaeParams p, con
     LT_STAMP(5);
 }
 
+// ------------------------------------------------------------------------------------------ register-resident forward
+// The streaming kernel above reads x three times (statistics, scores, z): a 64-pixel tile is 1 MB and fits nowhere on the
+// CU.  A 16-pixel tile is 250 KB -- half of the CU's register file -- so here x is read from HBM ONCE and stays in
+// registers; everything else (attention weights, partial sums) moves through LDS.  HBM traffic is the algorithmic
+// minimum: x in, attn / attn_pre / emb out.
+//
+//   workgroup = 8 waves on one tile of 16 adjacent pixels; lane = (px = lane & 15, q = lane >> 4);
+//   wave w owns time steps 8w..8w+7; lane q owns channels 16q..16q+15 (GroupNorm groups 4q..4q+3, complete in the lane):
+//   x[8 t][16 c] = 128 registers per lane.  A 64-byte row segment per (t, c) row and quarter-wave.
+//
+//   F1 load        128 independent dword loads per lane
+//   F2 statistics  exact two-pass (mean, then squared deviations) with two 8-wave sums through LDS; normalise in place
+//   F3 scores      v_mfma_f32_16x16x4: A = U [16 heads x 4 channels], B = xhat [4 channels x 16 pixels] -- the k index of the
+//                  B operand is the lane quarter, so step s multiplies channels {s, 16+s, 32+s, 48+s}: 16 MFMAs per time
+//                  step, the sum over the four quarters happens inside the MFMA.  D: lane (px, q) gets heads 4q..4q+3.
+//   F4 softmax     over T: wave-local over its 8 steps, then max / sum across the 8 waves through LDS; dropout;
+//                  attn, attn_pre to HBM; the post-dropout weights also to LDS  adL[t][h][px]
+//   F5 pe / sum    ape[h][j][px] = sum_t a pe_t[j],  asum = sum_t a   (thread = (px, h, half of j); pe through the scalar cache)
+//   F6 z, emb      8 rounds of 2 heads: every lane accumulates z[h][its 16 channels] over its 8 time steps (VALU), the 8
+//                  wave-partials are summed through LDS, and one wave per head multiplies by Wc on the MFMA
+//                  (A = Wc rows, B = z [4 channels x 16 pixels]) and stores emb.
+constexpr int RPX = 16, RZP = 17;
+constexpr int R_TP = 272;                          // adL pitch per time step: 16 px x 16 heads + 16 (the MFMA A reads of 4 steps hit 64 banks)
+constexpr int R_XT = 80;                           // xs pitch per time step: 64 c + 16 (the MFMA B reads of 4 steps hit 64 banks)
+constexpr int R_XP = 16 * R_XT + 4;                // xs pitch per pixel (= 4 mod 64: the 16-byte stores of 16 lanes hit 64 banks)
+constexpr int R_XB = 16 * R_XP;                    // the xs buffer: 16 pixels x 16 time steps
+constexpr int R_ZH = 64 * RZP + 4;                 // zT pitch per head (= 4 mod 16: the transposing stores of the 4 lane quarters spread)
+constexpr int R_AH = 16 * RZP + 4;                 // apeT pitch per head
+constexpr int R_AD = 0;                            // adL [64 t][16 px][16 h] (pitch R_TP);  later zT [16 h][64 c][RZP] (pitch R_ZH)
+constexpr int R_XS = R_AD + 16 * R_ZH;             // xs [16 px][16 t][64 c]: a quarter of the time steps; before: red [2][8][16][16]; later apeT
+constexpr int R_AS = R_XS + R_XB;                  // asum partials [8 w][16 h][16 px]
+constexpr int R_FLOATS = R_AS + 8 * 16 * 16;       // 40,064 floats = 160,256 bytes
+static_assert(16 * R_ZH >= 64 * R_TP && R_XB >= 16 * R_AH && R_XB >= 2 * 8 * 16 * 16, "LDS map of the register-resident forward");
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)):
+// in this kernel no wave reads what another one stored to global memory, so the attention rows written in F4 may stay in
+// flight while the next phases run (3.4k cycles of every tile went into that drain).
+__device__ __forceinline__ void lds_barrier() {
+#ifdef C2S_REG_SYNCTHREADS
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+__global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
+    extern __shared__ float lds[];
+    float* adL = lds + R_AD;
+    float* xs = lds + R_XS;
+    float* asp = lds + R_AS;
+    float* red = xs;                               // the small cross-wave reductions are over before xs is used
+    constexpr int C = 64;
+    const int T = p.T, HW = p.HW;
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave index as a scalar: row addresses become SGPR bases
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin, so give each XCD a contiguous eighth of the tiles --
+    // the two 16-pixel tiles that share every 128-byte line of x then sit behind the same L2.
+    // (A persistent tile loop was tried: the loop-carried state pushed the kernel from 234 to 256 VGPRs + 65 spills, 1.39 -> 2.07 ms.)
+    unsigned tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
+    const int tiles_per_b = HW / RPX;
+    const int b = (int)(tile / tiles_per_b);
+    const int pix = (int)(tile % tiles_per_b) * RPX + px;
+    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
+    const float* xb = p.x + (size_t)b * T * C * HW;                       // uniform base; 32-bit offsets below (< 2^30 floats)
+    const unsigned xoff = (unsigned)(16 * q) * (unsigned)HW + (unsigned)pix;
+    const int t0 = 8 * w;
+    const int nt = T - t0 < 0 ? 0 : (T - t0 < 8 ? T - t0 : 8);          // time steps of this wave that exist
+    LT_STAMP(0);
+    // ---- F1
+    float x[8][16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tc = t0 + i < T ? t0 + i : T - 1;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) x[i][s] = (xb + (size_t)(tc * C + s) * HW)[xoff];        // uniform row pointer + per-lane offset
+    }
+    // ---- F2: GroupNorm statistics over (4 channels x T), padded frames included (tae.py:461): exact two-pass moments of the
+    // wave's own 4 nt values per group, then ONE exchange: every wave merges the 8 (count, mean, M2) partials with Chan's update
+    // in the same order (identical results in all waves, independent of the data).
+    {
+        float* red2 = red + 8 * 16 * 16;
+        float mean[4], rs[4];
+        const float inv_cw = nt > 0 ? __frcp_rn((float)(4 * nt)) : 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nt) s1 += (x[i][4 * gg] + x[i][4 * gg + 1]) + (x[i][4 * gg + 2] + x[i][4 * gg + 3]);
+            const float mw = s1 * inv_cw;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nt) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const float d = x[i][4 * gg + cc] - mw;
+                        s2 = fmaf(d, d, s2);
+                    }
+                }
+            red[(w * 16 + 4 * q + gg) * 16 + px] = mw;
+            red2[(w * 16 + 4 * q + gg) * 16 + px] = s2;
+        }
+        lds_barrier();
+        // merge weights of partial ww (functions of T only): r1 = n_b / (n + n_b), r2 = n n_b / (n + n_b)
+        float r1[8], r2[8];
+        {
+            float cnt = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const int ntw = T - 8 * ww < 0 ? 0 : (T - 8 * ww < 8 ? T - 8 * ww : 8);
+                const float nb = (float)(4 * ntw), tot = cnt + nb;
+                const float inv = tot > 0.f ? __frcp_rn(tot) : 0.f;
+                r1[ww] = nb * inv;
+                r2[ww] = cnt * nb * inv;
+                cnt = tot;
+            }
+        }
+        const float inv_n = __frcp_rn((float)(4 * T));
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            float mean_ = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const float mb = red[(ww * 16 + 4 * q + gg) * 16 + px], qb = red2[(ww * 16 + 4 * q + gg) * 16 + px];
+                const float delta = mb - mean_;          // an empty partial (T <= 8 ww) has r1 = r2 = 0 and qb = 0
+                mean_ = fmaf(delta, r1[ww], mean_);
+                m2 += fmaf(delta * delta, r2[ww], qb);
+            }
+            mean[gg] = mean_;
+            rs[gg] = rsqrtf(fmaf(m2, inv_n, p.eps));
+            if (w == 0) {
+                p.stats[(pidx * NH + 4 * q + gg) * 2] = mean[gg];
+                p.stats[(pidx * NH + 4 * q + gg) * 2 + 1] = rs[gg];
+            }
+        }
+        // normalise in place: xhat = (x - mean) * (rstd * gamma) + beta
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a = rs[s >> 2] * p.gamma[16 * q + s], bt = p.beta[16 * q + s], m = mean[s >> 2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i][s] = fmaf(x[i][s] - m, a, bt);
+        }
+    }
+    LT_STAMP(1);
+    // ---- F3: scores on the MFMA
+    // operands of the softmax phase, requested here so that their latency hides behind the MFMAs (earlier they would hold 40
+    // registers through the statistics): s0[b][t][4q..4q+3] (one 16-byte load per time step) and the per-frame padding flags
+    f32x4 s0v[8];
+    int vflag[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tc = t0 + i < T ? t0 + i : T - 1;
+        s0v[i] = *reinterpret_cast<const f32x4*>(p.s0 + (size_t)(b * T + tc) * NH + 4 * q);
+        vflag[i] = p.valid != nullptr ? p.valid[b * T + tc] : 1;
+    }
+    float sc[8][4];
+    {
+        float Ua[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) Ua[s] = p.U[px * C + 16 * q + s];      // A[i = head px][k = q] of step s
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ua[s], x[i][s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[i][r] = acc[r];                   // head 4q + r, pixel px
+        }
+    }
+    LT_STAMP(2);
+    // ---- F4: softmax over T (masked, tae.py:831), dropout, outputs
+    {
+        float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = vflag[i] == 0 ? -1e6f : sc[i][r] + s0v[i][r];
+                    sc[i][r] = v;
+                    mx[r] = fmaxf(mx[r], v);
+                }
+            }
+        // local softmax pieces of the wave's 8 steps, then ONE exchange: M = max_w m_w, S = sum_w s_w exp(m_w - M)
+        float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(sc[i][r] - mx[r]);
+                    sc[i][r] = e;
+                    sm[r] += e;
+                }
+            }
+        float* red2 = red + 8 * 16 * 16;
+        lds_barrier();                             // the statistics partials in `red` have been read by every wave
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(w * 16 + 4 * q + r) * 16 + px] = mx[r];
+            red2[(w * 16 + 4 * q + r) * 16 + px] = sm[r];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mw[8], m = -3.0e38f, d = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                mw[ww] = red[(ww * 16 + 4 * q + r) * 16 + px];
+                m = fmaxf(m, mw[ww]);
+            }
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) d = fmaf(red2[(ww * 16 + 4 * q + r) * 16 + px], __expf(mw[ww] - m), d);
+            sm[r] = __expf(mx[r] - m) / d;         // a = exp(v - m_w) * exp(m_w - M) / S
+        }
+        // output rows: uniform base (b, t) + per-lane offset (head, pixel); 32-bit offsets (the host checks 16*B*T*HW < 2^30)
+        unsigned hoff[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hoff[r] = (unsigned)(4 * q + r) * (unsigned)(p.B * T) * (unsigned)HW + (unsigned)pix;
+        const bool rng = p.drop_p > 0.f && p.keep == nullptr;
+        DropCtx dc = {};
+        if (rng) dc = drop_ctx(p);
+        // head by head (4 hashes live at a time): t0 is even, so steps (2u, 2u+1) of a row share one hash
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = 4 * q + r;
+            uint32_t bits[4] = {0u, 0u, 0u, 0u};
+            if (rng) {
+                const uint64_t rb = (uint64_t)((long)h * Ptot + pidx) * (uint64_t)dc.half_t + (uint64_t)(t0 >> 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t i2 = rb + (uint64_t)u;
+                    bits[u] = c2s_hash32((uint32_t)i2 ^ dc.key ^ (uint32_t)(i2 >> 32) * 0x85EBCA6Bu);
+                }
+            }
+            float as = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float ad = 0.f;                    // steps T..63 carry zero weight
+                if (i < nt) {
+                    const int t = t0 + i;
+                    const float a = sc[i][r] * sm[r];
+                    const float ks = rng ? drop_pick(dc, bits[i >> 1], t) : keep_scale(p, h, Ptot, pidx, t);
+                    ad = a * ks;
+                    if (p.attn_pre != nullptr) (p.attn_pre + (size_t)(b * T + t) * HW)[hoff[r]] = a;
+                    (p.attn + (size_t)(b * T + t) * HW)[hoff[r]] = ad;
+                    as += ad;
+                }
+                sc[i][r] = ad;
+            }
+            asp[(w * 16 + h) * 16 + px] = as;      // sum_t a, per wave (summed in the epilogue)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f32x4*>(adL + (t0 + i) * R_TP + px * 16 + 4 * q) = (f32x4){sc[i][0], sc[i][1], sc[i][2], sc[i][3]};
+    }
+    if (p.emb == nullptr) return;                  // attention masks only (tae.py:619)
+    lds_barrier();
+    LT_STAMP(3);
+
+    // ---- F5: z[h][c] = sum_t a[h][t] xhat[t][c] PER PIXEL on the MFMA:  A = a_px [16 h x 4 t] from adL,  B = xhat_px [4 t x 16 c].
+    // The B operand of one pixel is spread over lanes and waves, so xhat goes through LDS, 16 time steps (two waves' registers,
+    // full-wave 16-byte stores) at a time; every wave multiplies two pixels x four channel blocks per quarter and keeps the
+    // eight accumulators.  D: lane (n = c - 16 cb, rows h = 4q + r).
+    // (Tried: staging by channel quarter with 16 active lanes per store, 24.8k cycles per tile; one wave staging its 8 steps into a
+    // second buffer while the others multiply, one barrier per chunk, 19.8k; this form 16.3k.)
+    const int hl = px;                             // the lane's row index of an A operand / column index of a B operand
+    f32x4 zacc[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) { zacc[cb][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; zacc[cb][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float pb[16];                                  // B operand of the pe product and the operands of the embedding GEMM: requested
+    f32x4 wa[2][4], bcv[2];                        // after the last quarter is staged (x is dead then), used after the loop
+    const float* ap0 = adL + q * R_TP + (2 * w) * 16 + hl;               // A operand of pixel 2w: + t R_TP; pixel 2w+1: + 16
+    const float* bp0 = xs + (2 * w) * R_XP + q * R_XT + hl;              // B operand of pixel 2w: + 4 s R_XT + 16 cb; pixel 2w+1: + R_XP
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        if ((w >> 1) == tq) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<f32x4*>(xs + px * R_XP + (8 * (w & 1) + i) * R_XT + 16 * q + 4 * u) =
+                        (f32x4){x[i][4 * u], x[i][4 * u + 1], x[i][4 * u + 2], x[i][4 * u + 3]};
+        }
+        if (tq == 3) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int t = 4 * s + q;
+                pb[s] = t < T ? p.pe[(size_t)(b * T + t) * DV + hl] : 0.f;
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4* wr = reinterpret_cast<const f32x4*>(p.Wc + (size_t)((2 * w + hh) * DV + px) * C + 16 * q);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wa[hh][u] = wr[u];
+                bcv[hh] = *reinterpret_cast<const f32x4*>(p.bc + (2 * w + hh) * DV + 4 * q);
+            }
+        }
+        lds_barrier();
+        // operands first (8 A + 32 B values), then the 32 MFMAs: 8 independent chains of 4
+        float av[2][4], bv[2][4][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                av[u][s] = ap0[(16 * tq + 4 * s) * R_TP + 16 * u];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) bv[u][cb][s] = bp0[4 * s * R_XT + 16 * cb + R_XP * u];
+            }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    zacc[cb][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], bv[u][cb][s], zacc[cb][u], 0, 0, 0);
+        lds_barrier();
+    }
+    LT_STAMP(4);
+    // the same with B = pe[b][t][j] (shared by all pixels):  ape[h][j] = sum_t a[h][t] pe_t[j];   D: lane (n = j, rows h = 4q + r)
+    f32x4 pacc[2];
+    {
+        float av[2][16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) av[u][s] = ap0[4 * s * R_TP + 16 * u];        // a[h][t = 4s + q] of pixel 2w + u
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], pb[s], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s + 1], pb[s + 1], d1, 0, 0, 0);
+            }
+            pacc[u] = d0 + d1;
+        }
+    }
+    lds_barrier();                               // every MFMA above has read adL: zT takes its place, apeT that of xs
+    float* zT = lds + R_AD;
+    float* apeT = lds + R_XS;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) zT[(4 * q + r) * R_ZH + (16 * ch + hl) * RZP + 2 * w + u] = zacc[ch][u][r];
+            apeT[(4 * q + r) * R_AH + hl * RZP + 2 * w + u] = pacc[u][r];
+        }
+    }
+    lds_barrier();
+    LT_STAMP(5);
+    // ---- F6: emb[16h+j][px] = sum_c Wc[16h+j][c] z[h][c][px] + (sum_t a) bc[16h+j] + ape[h][j][px];  step s multiplies channels
+    // 16k + s (k = lane quarter):  A[i = j][k] = Wc[16h + j][16k + s],  B[k][n = px] = zT[h][16k + s][px]
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int hm = 2 * w + hh;
+        const float* zb = zT + hm * R_ZH + (16 * q) * RZP + px;
+        f32x4 dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dd[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dd[s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[hh][s >> 2][s & 3], zb[s * RZP], dd[s & 3], 0, 0, 0);
+        float as = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) as += asp[(ww * 16 + hm) * 16 + px];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dsum = (dd[0][r] + dd[1][r]) + (dd[2][r] + dd[3][r]);
+            p.emb[((size_t)b * NH * DV + hm * DV + 4 * q + r) * HW + pix] = dsum + fmaf(as, bcv[hh][r], apeT[hm * R_AH + (4 * q + r) * RZP + px]);
+        }
+    }
+    LT_STAMP(6);
+}
+
 // ------------------------------------------------------------------------------------------ streaming backward
 // Same idea as the streaming forward, 32-pixel tiles: lane = (pixel, half), 16 waves per workgroup, the role of a wave
 // changes per phase.  Two kernels (x is read three times in total):
@@ -1696,6 +2097,7 @@ void init_hook() {
     C2S_RAISE_LDS(ltae_bwd_gx_kernel);
     C2S_RAISE_LDS(ltae_stream_bwd_heads_kernel<4>);
     C2S_RAISE_LDS(ltae_stream_bwd_gx_kernel<4>);
+    C2S_RAISE_LDS(ltae_reg_fwd_kernel);
 }
 C2sInitRegistrar registrar(init_hook);
 
@@ -1721,7 +2123,17 @@ static bool use_stream(const c2s_ltae_desc* d) {
     return d->C == 64 && (long)d->B * ((d->HW + 63) / 64) >= 2L * cus;
 }
 
-extern "C" int c2s_ltae_uses_streaming(const c2s_ltae_desc* d) { return d && check(d) == C2S_OK && use_stream(d) ? 1 : 0; }
+// The register-resident forward (16-pixel tiles, x read once) needs C == 64 and whole tiles; it pays off as soon as the tiles
+// fill the chip a few times over.  C2S_LTAE_REG=0 keeps the three-pass streaming kernel (A/B runs).
+static bool use_reg_fwd(const c2s_ltae_desc* d) {
+    static const bool enabled = [] { const char* e = getenv("C2S_LTAE_REG"); return !(e && e[0] == '0'); }();
+    return enabled && d->C == 64 && d->HW % RPX == 0 && (long)d->B * (d->HW / RPX) >= 4L * c2s_cus() &&
+           (long)NH * d->B * d->T * d->HW < (1L << 30);             // 32-bit element offsets into attn
+}
+
+extern "C" int c2s_ltae_uses_streaming(const c2s_ltae_desc* d) {
+    return d && check(d) == C2S_OK && (use_stream(d) || use_reg_fwd(d)) ? 1 : 0;
+}
 
 extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                                     const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
@@ -1735,6 +2147,11 @@ extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, cons
     p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.s0 = s0; p.Wc = Wc; p.bc = bc; p.pe = pe; p.valid = valid;
     p.attn = attn; p.attn_pre = attn_pre; p.emb = emb; p.stats = stats;
     hipStream_t st = (hipStream_t)stream;
+    if (use_reg_fwd(d)) {
+        hipLaunchKernelGGL(ltae_reg_fwd_kernel, dim3(d->B * (d->HW / RPX)), dim3(512), R_FLOATS * sizeof(float), st, p);
+        C2S_CHECK_LAUNCH("ltae_reg_fwd");
+        return C2S_OK;
+    }
     if (workspace != nullptr && attn_pre != nullptr && use_stream(d)) {
         C2S_REQUIRE(ws_floats >= c2s_ltae_fwd_workspace_floats(d), "ltae_fwd: workspace too small");
         float* Ut = workspace;
