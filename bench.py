@@ -209,7 +209,8 @@ def main():
         ms = [a.elapsed_time(b) for a, b in prof["events"]]
         kernel_ms = sum(ms) / max(len(ms), 1)
         N = B * T
-        flops_algo = 2.0 * N * 64 * 64 * 9 * H * H                    # direct-convolution FLOPs of one launch
+        n_real = sum(lengths)                                          # padded frames are skipped by the per-frame kernels
+        flops_algo = 2.0 * n_real * 64 * 64 * 9 * H * H               # direct-convolution FLOPs of one launch
         wino = E.WINOGRAD and E.CONV_MODE == "f32"
         # FLOPs the kernel actually issues on the MFMA pipe: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 output block
         # where the direct form needs 36 -- the roofline fraction is priced on the EXECUTED count (<= 1 by construction)
@@ -220,8 +221,8 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_F32_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": 2.0 * N * 64 * H * H * 4 + 64 * 64 * 9 * 4,
-                    "kernel": kname + f" 64->64 3x3 reflect @{H}x{H}, N={N} frames (forward launches of the in_conv block; the "
+                    "algorithmic_bytes_per_launch": 2.0 * n_real * 64 * H * H * 4 + 64 * 64 * 9 * 4,
+                    "kernel": kname + f" 64->64 3x3 reflect @{H}x{H}, N={N} frames of which {n_real} real (forward launches of the in_conv block; the "
                               "data-gradient launches of the same kernel share the GPU with the weight gradients of the side "
                               "stream, so their event-to-event time is not the kernel's own)",
                     "launches_timed": len(ms), "avg_launch_ms": kernel_ms,
@@ -244,7 +245,7 @@ def main():
                              "kernel": "ltae_stream_fwd (prep + streaming forward, one call)", "avg_launch_ms": lavg,
                              "launches_timed": len(lms), "algorithmic_bytes_per_launch": lbytes}
         a_, b_ = STEP_FLOPS[args.model]
-        step_flops = (a_ * T + b_) * H * H * 3.0
+        step_flops = (a_ * (n_real / B) + b_) * H * H * 3.0           # per-frame terms scale with the real frames of a patch
         cfg_id = {("utae", 4, 32, 128): "BASELINE.json configs[1] shape (fp32 instead of the bf16 named there: the reference is fp32-only)",
                   ("timeunet", 8, 61, 128): "BASELINE.json configs[2] shape",
                   ("wtae", 4, 32, 128): "BASELINE.json configs[3] per-GPU shape",

@@ -36,6 +36,7 @@ class BackboneSpec:
     d_k: int = 4
     pad_value: float = 0.0
     padding_mode: str = "reflect"
+    conv_type: str = "2d"             # "depthwise_separable": in_conv and the down blocks use DepthwiseSeparableConv2D (utae.py:144,158)
     add_boundary_loss: bool = False   # second (2-class) head on the last decoder map (reference utae.py:195-198,236-244)
     encoder: bool = False             # return (last decoder map, maps) instead of logits (utae.py:233-234)
     return_maps: bool = False         # also return the decoder feature maps (utae.py:224-231)
@@ -59,7 +60,9 @@ def _mode(spec: BackboneSpec) -> int:
 
 
 def _norm_kind(norm: str) -> int:
-    return _lib.NORM_GROUP if norm == "group" else _lib.NORM_BATCH
+    if norm not in ("group", "batch", "instance"):
+        raise NotImplementedError(f"norm {norm!r}")
+    return _lib.NORM_BATCH if norm == "batch" else _lib.NORM_GROUP
 
 
 def conv_layer(ctx: E.Ctx, srcs: Sequence[Tensor], prefix: str, n_convs: int, norm: str, k: int, s: int, p: int,
@@ -81,15 +84,18 @@ def conv_layer(ctx: E.Ctx, srcs: Sequence[Tensor], prefix: str, n_convs: int, no
                          need_input_grad=need_input_grad or i > 0)
             bias = cp + ".bias"
         last = i == n_convs - 1
-        y = E.norm_act(ctx, y, f"{prefix}.conv.{3 * i + 1}", _norm_kind(norm), 4, True, residual if last else None,
-                       valid, spec.pad_value if valid is not None else 0.0, conv_bias=bias)
+        # "instance" = nn.InstanceNorm2d (conv.py:54-55): one group per channel, no affine parameters, no running statistics
+        y = E.norm_act(ctx, y, f"{prefix}.conv.{3 * i + 1}", _norm_kind(norm), y.shape[1] if norm == "instance" else 4, True,
+                       residual if last else None, valid, spec.pad_value if valid is not None else 0.0, conv_bias=bias,
+                       affine=norm != "instance")
         x = [y]
     return y
 
 
-def conv_block(ctx, x, prefix, n_convs, norm, spec, valid, need_input_grad=True):
+def conv_block(ctx, x, prefix, n_convs, norm, spec, valid, need_input_grad=True, depthwise_separable=False):
     """ConvBlock (reference conv.py:168-200)."""
-    return conv_layer(ctx, [x], prefix + ".conv", n_convs, norm, 3, 1, 1, spec, valid, need_input_grad=need_input_grad)
+    return conv_layer(ctx, [x], prefix + ".conv", n_convs, norm, 3, 1, 1, spec, valid, need_input_grad=need_input_grad,
+                      depthwise_separable=depthwise_separable)
 
 
 def down_conv_block(ctx, x, prefix, norm, spec, valid, depthwise_separable=False):
@@ -166,11 +172,12 @@ def utae_forward(ctx, spec, x5, dates, drop):
     """UTAE.forward (reference utae.py:200-252), default flags."""
     B, T = x5.shape[:2]
     valid = E.frame_flags(x5, spec.pad_value)
-    f = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False)
+    dws = spec.conv_type == "depthwise_separable"
+    f = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws)
     fmaps = [f]
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):
-        f = down_conv_block(ctx, f, f"down_blocks.{i}", spec.encoder_norm, spec, valid)
+        f = down_conv_block(ctx, f, f"down_blocks.{i}", spec.encoder_norm, spec, valid, depthwise_separable=dws)
         fmaps.append(f)
     out, att = ltae(ctx, _unfold(fmaps[-1], B, T), dates, valid, "temporal_encoder", spec, drop, True)
     skips = [E.temporal_aggregate(ctx, _unfold(fmaps[-(i + 2)], B, T), att, valid, spec.n_head, spec.agg_mode)
@@ -182,12 +189,13 @@ def timeunet_forward(ctx, spec, x5, dates, drop):
     """TimeUNet_v1.forward (reference timeunet.py:169-210)."""
     B, T = x5.shape[:2]
     valid = E.frame_flags(x5, spec.pad_value)
-    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False)
+    dws = spec.conv_type == "depthwise_separable"
+    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws)
     out, att = ltae(ctx, _unfold(f0, B, T), dates, valid, "temporal_encoder", spec, drop, True)
     fmaps = [out]
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):
-        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None))
+        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None, depthwise_separable=dws))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(ctx, fmaps[-1], skips, spec, att)
 
@@ -196,7 +204,8 @@ def wtae_forward(ctx, spec, x5, dates, drop):
     """WTAE.forward (reference wtae.py:220-279)."""
     B, T = x5.shape[:2]
     valid = E.frame_flags(x5, spec.pad_value)
-    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False)
+    dws = spec.conv_type == "depthwise_separable"
+    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws)
     red = f0
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):
@@ -204,7 +213,7 @@ def wtae_forward(ctx, spec, x5, dates, drop):
     _, att = ltae(ctx, _unfold(red, B, T), dates, valid, "temporal_encoder", spec, drop, False)
     fmaps = [E.temporal_aggregate(ctx, _unfold(f0, B, T), att, valid, spec.n_head, spec.agg_mode)]
     for i in range(n_stages - 1):
-        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None))
+        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None, depthwise_separable=dws))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(ctx, fmaps[-1], skips, spec, att)
 

@@ -64,8 +64,10 @@ class ConvLayer(_Holder):
                 layers.append(nn.BatchNorm2d(nkernels[i + 1]))
             elif norm == "group":
                 layers.append(nn.GroupNorm(num_channels=nkernels[i + 1], num_groups=n_groups))
+            elif norm == "instance":
+                layers.append(nn.InstanceNorm2d(nkernels[i + 1]))       # no parameters, no buffers (conv.py:54-55)
             else:
-                raise NotImplementedError(f"norm={norm!r}: crop2seg_amd builds 'group' and 'batch'")
+                raise NotImplementedError(f"norm={norm!r}: crop2seg_amd builds 'group', 'batch' and 'instance'")
             layers.append(nn.ReLU())
         self.conv = nn.Sequential(*layers)
 
@@ -294,10 +296,11 @@ def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_con
     unsupported = dict(use_mbconv=use_mbconv, add_squeeze_excit=add_squeeze_excit, use_abs_rel_enc=use_abs_rel_enc,
                        use_doy=use_doy, add_linear=add_linear)
     bad = [k for k, v in unsupported.items() if v]
-    if bad or num_queries != 1 or conv_type != "2d" or agg_mode not in ("att_group", "att_mean", "mean"):
+    if bad or num_queries != 1 or conv_type not in ("2d", "depthwise_separable") or agg_mode not in ("att_group", "att_mean", "mean"):
         raise NotImplementedError(
             "crop2seg_amd builds the reference's default blocks (train.py:32-47,153-166) plus agg_mode in {att_group, att_mean, "
-            "mean}, add_boundary_loss, encoder and return_maps; not built: "
+            "mean}, conv_type in {2d, depthwise_separable}, encoder_norm in {group, batch, instance}, add_boundary_loss, encoder and "
+            "return_maps; not built: "
             f"{bad or dict(num_queries=num_queries, conv_type=conv_type, agg_mode=agg_mode)}")
     if encoder:
         return_maps = True                      # utae.py:129-130
@@ -318,7 +321,7 @@ def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_con
                                 decoder_widths=list(decoder_widths), out_conv=list(out_conv), str_conv_k=str_conv_k,
                                 str_conv_s=str_conv_s, str_conv_p=str_conv_p, agg_mode=agg_mode,
                                 encoder_norm=encoder_norm, n_head=n_head, d_model=d_model, d_k=d_k,
-                                pad_value=float(pad_value), padding_mode=padding_mode,
+                                pad_value=float(pad_value), padding_mode=padding_mode, conv_type=conv_type,
                                 add_boundary_loss=bool(add_boundary_loss), encoder=bool(encoder),
                                 return_maps=bool(return_maps))
     self.add_boundary_loss = bool(add_boundary_loss)
@@ -354,9 +357,9 @@ class UTAE(_Backbone):
                                       return_maps, pad_value, padding_mode, conv_type, use_mbconv, add_squeeze_excit,
                                       use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss)
         self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
-                                 norm=encoder_norm, padding_mode=padding_mode)
+                                 norm=encoder_norm, padding_mode=padding_mode, conv_type=conv_type)
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
-                                       padding_mode)
+                                       padding_mode, conv_type=conv_type)
         self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
         self.temporal_encoder = LTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
@@ -381,9 +384,9 @@ class TimeUNet_v1(_Backbone):
                                       add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear,
                                       False)                                                     # swallowed by **kwargs in the reference
         self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
-                                 norm=encoder_norm, padding_mode=padding_mode)
+                                 norm=encoder_norm, padding_mode=padding_mode, conv_type=conv_type)
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
-                                       padding_mode)
+                                       padding_mode, conv_type=conv_type)
         self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
         self.temporal_encoder = LTAE(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
                                      mlp=[d_model, encoder_widths[0]])
@@ -404,11 +407,11 @@ class WTAE(_Backbone):
                                       return_maps, pad_value, padding_mode, conv_type, use_mbconv, add_squeeze_excit,
                                       use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss)
         self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
-                                 norm=encoder_norm, padding_mode=padding_mode)
+                                 norm=encoder_norm, padding_mode=padding_mode, conv_type=conv_type)
         self.spatial_reduction = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
                                              padding_mode, conv_type="depthwise_separable")
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
-                                       padding_mode)
+                                       padding_mode, conv_type=conv_type)
         self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
         self.temporal_encoder = LTAE4WTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)

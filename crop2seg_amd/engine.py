@@ -554,15 +554,22 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
 # normalisation (+ReLU, +residual)
 # =================================================================================================
 def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: bool, residual: Optional[Tensor],
-             valid: Optional[Tensor], pad_value: float = 0.0, conv_bias: Optional[str] = None) -> Tensor:
+             valid: Optional[Tensor], pad_value: float = 0.0, conv_bias: Optional[str] = None, affine: bool = True) -> Tensor:
     """GroupNorm / BatchNorm (+ReLU) (+ residual add) on NCHW x.  `conv_bias` names the bias of the convolution
-    that produced x: its gradient (= per-channel sum of dx) falls out of the same reduction."""
+    that produced x: its gradient (= per-channel sum of dx) falls out of the same reduction.  affine=False: no learnable
+    gain / shift (nn.InstanceNorm2d): the kernels run with constant ones / zeros and their gradients are discarded."""
     N, Cc = x.shape[0], x.shape[1]
     HW = x[0, 0].numel()
     batch = kind == _lib.NORM_BATCH
     training = 1 if (ctx.training or not batch) else 0
     d = NormDesc(N, Cc, HW, kind, groups if not batch else 1, training if batch else 1, ctx.eps, ctx.momentum)
-    gamma, beta = ctx.p[prefix + ".weight"], ctx.p[prefix + ".bias"]
+    if affine:
+        gamma, beta = ctx.p[prefix + ".weight"], ctx.p[prefix + ".bias"]
+    else:
+        gamma = ctx.ws.get(f"ones{Cc}", Cc)
+        beta = ctx.ws.get(f"zeros{Cc}", Cc)
+        check(lib().c2s_fill(gamma.data_ptr(), Cc, 1.0, _stream()), "fill")
+        check(lib().c2s_fill(beta.data_ptr(), Cc, 0.0, _stream()), "fill")
     rm = ctx.b.get(prefix + ".running_mean") if batch else None
     rv = ctx.b.get(prefix + ".running_var") if batch else None
     ngroups = Cc if batch else N * groups
@@ -589,8 +596,12 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
             gx = torch.empty_like(g)                  # ... and the norm gradient goes to a fresh buffer (no copy of g)
         else:
             gx = g  # in place
-        dgamma, _ = ctx.grad_sink(prefix + ".weight")
-        dbeta, _ = ctx.grad_sink(prefix + ".bias")
+        if affine:
+            dgamma, _ = ctx.grad_sink(prefix + ".weight")
+            dbeta, _ = ctx.grad_sink(prefix + ".bias")
+        else:
+            dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
         dbias = ctx.grad_sink(conv_bias)[0] if conv_bias else None
         if SIDE_WGRAD and not torch.cuda.is_current_stream_capturing():
             # the parameter gradients (one wave per channel: a launch that leaves the GPU idle) go to the side stream; their

@@ -58,6 +58,7 @@ class BackboneConfig:
     d_k: int = 4
     pad_value: Optional[float] = 0.0
     padding_mode: str = "reflect"
+    conv_type: str = "2d"                    # "depthwise_separable": in_conv and the down blocks (utae.py:144,158; conv.py:66-71)
     add_boundary_loss: bool = False          # second head boundary_conv = ConvBlock([dec0, 32, 2]) (utae.py:195-198)
     boundary_gamma: float = 2.0              # FocalCELoss(gamma=2.0) (src/learning/utils.py:259)
     pe_period: float = 1000.0                # PositionalEncoder T (positional_encoding.py:11)
@@ -188,10 +189,10 @@ def shared_over_time(fn, x: Tensor, pad_value: Optional[float]) -> Tensor:
 
 
 def conv_block(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, cfg: BackboneConfig,
-               training: bool, bn: Optional[BNState], pad_value: Optional[float]) -> Tensor:
+               training: bool, bn: Optional[BNState], pad_value: Optional[float], depthwise_separable: bool = False) -> Tensor:
     """ConvBlock (conv.py:168-200) applied through smart_forward."""
     return shared_over_time(
-        lambda z: conv_layer(z, sd, prefix + ".conv", n_convs, norm, 3, 1, 1, cfg, training, bn),
+        lambda z: conv_layer(z, sd, prefix + ".conv", n_convs, norm, 3, 1, 1, cfg, training, bn, depthwise_separable),
         x, pad_value)
 
 
@@ -348,11 +349,12 @@ def utae_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, train
                  mlp_keep: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """UTAE.forward (utae.py:200-252), default flags.  Returns (logits, attn)."""
     pad_mask = frame_pad_mask(x, cfg.pad_value)
-    fmaps = [conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value)]
+    dws = cfg.conv_type == "depthwise_separable"
+    fmaps = [conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws)]
     n_stages = len(cfg.encoder_widths)
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(fmaps[-1], sd, f"down_blocks.{i}", cfg.encoder_norm, cfg, training, bn,
-                                     cfg.pad_value))
+                                     cfg.pad_value, dws))
     out, att = ltae(fmaps[-1], dates, pad_mask, sd, "temporal_encoder", cfg, training, bn, attn_keep, mlp_keep)
     skips = [temporal_aggregate(fmaps[-(i + 2)], pad_mask, att, cfg.agg_mode) for i in range(n_stages - 1)]
     return _decoder_and_head(out, skips, sd, cfg, training, bn), att
@@ -364,13 +366,14 @@ def timeunet_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, t
     """TimeUNet_v1.forward (timeunet.py:169-210): in_conv per frame -> L-TAE at full resolution
     -> plain U-Net on the single aggregated image (down blocks see 4-D input)."""
     pad_mask = frame_pad_mask(x, cfg.pad_value)
-    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value)
+    dws = cfg.conv_type == "depthwise_separable"
+    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws)
     out, att = ltae(f0, dates, pad_mask, sd, "temporal_encoder", cfg, training, bn, attn_keep, mlp_keep)
     fmaps = [out]
     n_stages = len(cfg.encoder_widths)
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(fmaps[-1], sd, f"down_blocks.{i}", cfg.encoder_norm, cfg, training, bn,
-                                     cfg.pad_value))
+                                     cfg.pad_value, dws))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(fmaps[-1], skips, sd, cfg, training, bn), att
 
@@ -380,7 +383,8 @@ def wtae_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, train
     """WTAE.forward (wtae.py:220-279): in_conv -> depthwise-separable spatial reduction ->
     attention masks (LTAE4WTAE) -> aggregate the full-resolution features -> plain U-Net."""
     pad_mask = frame_pad_mask(x, cfg.pad_value)
-    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value)
+    dws = cfg.conv_type == "depthwise_separable"
+    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws)
     red = f0
     n_stages = len(cfg.encoder_widths)
     for i in range(n_stages - 1):
@@ -390,7 +394,7 @@ def wtae_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, train
     fmaps = [temporal_aggregate(f0, pad_mask, att, cfg.agg_mode)]
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(fmaps[-1], sd, f"down_blocks.{i}", cfg.encoder_norm, cfg, training, bn,
-                                     cfg.pad_value))
+                                     cfg.pad_value, dws))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(fmaps[-1], skips, sd, cfg, training, bn), att
 

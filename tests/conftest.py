@@ -48,6 +48,17 @@ class Golden:
         self.attn_keep = torch.from_numpy(self.z["attn_keep"]) if "attn_keep" in self.z else None
         self.mlp_keep = torch.from_numpy(self.z["mlp_keep"]) if "mlp_keep" in self.z else None
 
+    def dummy_pass_pollutes(self, key):
+        """With encoder_norm='batch' the reference's smart_forward first runs the block on an all-zero dummy batch to learn
+        the output shape (temp_shared_block.py:24-26); in train mode that pass also updates the BatchNorm running statistics
+        of the per-frame encoder blocks (with the response to zeros) and counts as a batch.  Neither the oracle nor the
+        product has a dummy pass: outputs, loss and gradients are identical, those buffers are not."""
+        if self.ctor.get("encoder_norm") != "batch":
+            return False
+        shared = {"utae": ("in_conv.", "down_blocks."), "timeunet": ("in_conv.",),
+                  "wtae": ("in_conv.", "spatial_reduction.")}[self.cfg.model]
+        return key.startswith(shared)
+
     def dropout_kwargs(self):
         kw = {}
         if self.attn_keep is not None:

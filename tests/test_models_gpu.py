@@ -118,7 +118,7 @@ def test_model_matches_reference(goldens, name, conv_mode):
         assert len(g.soft_violations) <= 0.1 * len(names), g.soft_violations
         sd = net.state_dict()
         for k in g.z.files:
-            if k.startswith("bn/"):
+            if k.startswith("bn/") and not g.dummy_pass_pollutes(k[3:]):
                 ref = torch.from_numpy(g.z[k])
                 assert float((sd[k[3:]].cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), k
 

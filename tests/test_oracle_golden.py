@@ -50,7 +50,7 @@ def test_oracle_matches_reference_forward(goldens, name):
         assert torch.equal(logits.argmax(1), ref_logits.argmax(1))
     else:
         for k in g.z.files:
-            if k.startswith("bn/"):
+            if k.startswith("bn/") and not g.dummy_pass_pollutes(k[3:]):
                 ref = torch.from_numpy(g.z[k])
                 got = bn.updates[k[3:]]
                 assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max())), k
