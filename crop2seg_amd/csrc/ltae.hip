@@ -1657,33 +1657,6 @@ __device__ __forceinline__ void chunk_store(float* buf, const float (&v)[4], int
     }
 }
 
-// Deep chunks for the loops that run after r has moved to registers: SCB time steps of attn and gs of the tile's pixels as LDS
-// [arr 2][SCB][h/4][32 px][4] = 128 KB (the r area, dead by then): 2 x SCB x 16 rows of 32 pixels, 32 rows per (wave, half);
-// two barriers per 32 time steps instead of per 4 -- the loop in between streams x without synchronisation.
-constexpr int SCB = 32;
-// (loaded and stored in 4 parts of 8 rows: 32 values in flight per lane do not fit next to r and U in 128 registers)
-__device__ __forceinline__ void deep_chunk_part_load(const LtaeParams& p, float (&v)[8], int part, int b, int pix, int t0, int w,
-                                                     int hf, const float* gs_src) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (w * 2 + hf) * 32 + part * 8 + i;      // 0 .. 1023
-        const int arr = row >> 9, rem = row & 511;
-        const int tt = rem >> 4, h = rem & 15;
-        const int t = t0 + tt < p.T ? t0 + tt : p.T - 1;
-        const size_t o = ((size_t)(h * p.B + b) * p.T + t) * p.HW + pix;
-        v[i] = arr == 0 ? p.attn_in[o] : gs_src[o];
-    }
-}
-__device__ __forceinline__ void deep_chunk_part_store(float* buf, const float (&v)[8], int part, int w, int px, int hf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (w * 2 + hf) * 32 + part * 8 + i;
-        const int arr = row >> 9, rem = row & 511;
-        const int tt = rem >> 4, h = rem & 15;
-        buf[(((arr * SCB + tt) * 4 + (h >> 2)) * SPT + px) * 4 + (h & 3)] = v[i];
-    }
-}
-
 template <int CPG>
 __global__ __launch_bounds__(1024) void ltae_stream_bwd_heads_kernel(LtaeParams p, StreamBwd sb) {
     constexpr int C = CPG * NH;
@@ -1989,6 +1962,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, 
     constexpr int C = CPG * NH;
     extern __shared__ float lds[];
     float* rl = lds;                                          // [16 h][C/4][32 px][4]  r, as in the heads kernel (128 KB)
+    float* chk = rl + NH * C * SPT;                           // staged attn / gs chunk
     const int T = p.T, HW = p.HW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = lane & 31, hf = lane >> 5;
@@ -2027,74 +2001,214 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, 
     }
     __syncthreads();
     // r and U of the two channels of this lane (wave = group from here on)
-    float r[NH][2], u_[NH][2];
+    float r[NH][2], u[NH][2];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const f32x2s r2 = *reinterpret_cast<const f32x2s*>(rl + ((size_t)(h * (C / 4) + g) * SPT + px) * 4 + 2 * hf);
         r[h][0] = r2[0];
         r[h][1] = r2[1];
-        u_[h][0] = hf ? p.U[h * C + g * CPG + 2] : p.U[h * C + g * CPG + 0];
-        u_[h][1] = hf ? p.U[h * C + g * CPG + 3] : p.U[h * C + g * CPG + 1];
+        u[h][0] = hf ? p.U[h * C + g * CPG + 2] : p.U[h * C + g * CPG + 0];
+        u[h][1] = hf ? p.U[h * C + g * CPG + 3] : p.U[h * C + g * CPG + 1];
     }
     const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
     const float m1 = sb.M[(pidx * NH + g) * 2 + 0], m2 = sb.M[(pidx * NH + g) * 2 + 1];
     const float gm0 = (hf ? p.gamma[g * CPG + 2] : p.gamma[g * CPG]) * rstd, gm1 = (hf ? p.gamma[g * CPG + 3] : p.gamma[g * CPG + 1]) * rstd;
     const float* xg = p.x + (size_t)b * T * C * HW + (size_t)c0 * HW + pix;
     float* gxg = p.gx + (size_t)b * T * C * HW + (size_t)c0 * HW + pix;
-    __syncthreads();                                   // every lane has its r in registers: the area becomes the attn / gs chunk
-    float* dchk = rl;
-    for (int tc0 = 0; tc0 < T; tc0 += SCB) {
-        {
-            float sv[8];
-            deep_chunk_part_load(p, sv, 0, b, pix, tc0, w, hf, p.GS);
-            if (tc0 > 0) __syncthreads();              // previous chunk consumed
+    float sv[4], xn[SCH][2];
+    auto issue = [&](int t0) {
+        chunk_load(p, sv, b, pix, t0, w, hf, p.GS);
 #pragma unroll
-            for (int part = 0; part < 4; ++part) {
-                float nv[8];
-                if (part < 3) deep_chunk_part_load(p, nv, part + 1, b, pix, tc0, w, hf, p.GS);
-                deep_chunk_part_store(dchk, sv, part, w, px, hf);
+        for (int tt = 0; tt < SCH; ++tt) {
+            const int t = t0 + tt < T ? t0 + tt : T - 1;
+            xn[tt][0] = xg[(size_t)(t * C) * HW];
+            xn[tt][1] = xg[(size_t)(t * C + 1) * HW];
+        }
+    };
+    issue(0);
+    for (int t0 = 0; t0 < T; t0 += SCH) {
+        __syncthreads();
+        chunk_store(chk, sv, w, px, hf);
+        float xv[SCH][2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sv[i] = nv[i];
+        for (int tt = 0; tt < SCH; ++tt) { xv[tt][0] = xn[tt][0]; xv[tt][1] = xn[tt][1]; }
+        __syncthreads();
+        if (t0 + SCH < T) issue(t0 + SCH);
+#pragma unroll
+        for (int tt = 0; tt < SCH; ++tt) {
+            const int t = t0 + tt;
+            if (t < T) {
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int hq = 0; hq < 4; ++hq) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(chk + (((0 * SCH + tt) * 4 + hq) * SPT + px) * 4);
+                    const f32x4 gs = *reinterpret_cast<const f32x4*>(chk + (((1 * SCH + tt) * 4 + hq) * SPT + px) * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int h = hq * 4 + k;
+                        d0 = fmaf(a[k], r[h][0], d0); d0 = fmaf(gs[k], u[h][0], d0);
+                        d1 = fmaf(a[k], r[h][1], d1); d1 = fmaf(gs[k], u[h][1], d1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (act) {
+                    const float xn0 = (xv[tt][0] - mean) * rstd, xn1 = (xv[tt][1] - mean) * rstd;
+                    gxg[(size_t)(t * C) * HW] = gm0 * d0 - rstd * fmaf(xn0, m2, m1);
+                    gxg[(size_t)(t * C + 1) * HW] = gm1 * d1 - rstd * fmaf(xn1, m2, m1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ gx kernel, 64-pixel tiles
+// d x of the streaming backward with the lane = pixel / wave = GroupNorm group layout of the streaming forward:
+//   gx[t][c] = rstd (gamma_c sum_h (attn[h,t] r[h][c] + gs[h,t] U[h][c]) - m1 - xn[t][c] m2)
+// The 32-pixel kernel above keeps r AND U of (16 heads x 2 channels) in 64 VGPRs per lane and spills at the 128-register
+// limit of a 1024-thread workgroup (25 scratch reloads in its inner loops).  Here a wave owns ONE group, so U[h][4g..4g+3] is
+// wave-uniform (SGPR operands), only r[16][4] lives in VGPRs, rows are 256 bytes, and the attention / dscore rows of 16 time
+// steps are staged at once (128 KB, the area r passed through): two barriers per 16 steps instead of per 4.
+constexpr int GXT = 16;                            // time steps per staged chunk
+constexpr int GX_FLOATS = 2 * GXT * 4 * 64 * 4;    // [arr 2][GXT][h/4][64 px][4] = 32,768 floats = 128 KB
+
+__global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p, StreamBwd sb) {
+    constexpr int C = 64, CPG = 4;
+    extern __shared__ float lds[];                 // r of 8 heads [8][16 c4][64 px][4], then the attn / gs chunks
+    const int T = p.T, HW = p.HW;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);          // XCD-aware order
+    const int tiles_per_b = HW / 64;
+    const int b = (int)(tile / tiles_per_b);
+    const int pix = (int)(tile % tiles_per_b) * 64 + lane;
+    const long pidx = (long)b * HW + pix;
+    const int g = w;
+
+    // ---- r[h][c][px] = sum_j Wc[16h+j][c] ge[16h+j][px] on the MFMA, wave = head:  4 channel tiles x 4 pixel tiles x 4 k-steps
+    f32x4 d[4][4];
+    {
+        const int h = w, mi = lane & 15, mk = lane >> 4;
+        float gb_[4][4], wa_[4][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                gb_[ks][nt] = p.g_emb[((size_t)b * NH * DV + h * DV + 4 * ks + mk) * HW + (pix - lane) + nt * 16 + mi];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) wa_[ks][mt] = p.Wc[(size_t)(h * DV + 4 * ks + mk) * C + mt * 16 + mi];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_[ks][mt], gb_[ks][nt], acc, 0, 0, 0);
+                d[mt][nt] = acc;                   // rows c = 16 mt + 4 mk + r, column px = 16 nt + mi
+            }
+    }
+    // through LDS in two halves of 8 heads: [h & 7][c / 4][px][c & 3]; wave g then keeps r[16][4] of its group
+    float r[NH][CPG];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half == 1) __syncthreads();            // first half read
+        if ((w >> 3) == half) {
+            const int mi = lane & 15, mk = lane >> 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    *reinterpret_cast<f32x4*>(lds + ((size_t)((w & 7) * 16 + mt * 4 + mk) * 64 + nt * 16 + mi) * 4) = d[mt][nt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lds + ((size_t)(hh * 16 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int cc = 0; cc < CPG; ++cc) r[half * 8 + hh][cc] = v[cc];
+        }
+    }
+    const float mean = p.stats_in[(pidx * NH + g) * 2], rstd = p.stats_in[(pidx * NH + g) * 2 + 1];
+    const float m1 = sb.M[(pidx * NH + g) * 2 + 0], m2 = sb.M[(pidx * NH + g) * 2 + 1];
+    float gm[CPG];
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) gm[cc] = p.gamma[g * CPG + cc] * rstd;
+    // U[h][4g + cc] is wave-uniform: 64 scalar registers (readfirstlane pins them to SGPRs; left to the compiler they were
+    // re-loaded with vector loads inside the time loop because the gx stores might alias U)
+    float ug[NH][CPG];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int cc = 0; cc < CPG; ++cc)
+            ug[h][cc] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.U[h * C + g * CPG + cc])));
+    const float* xg = p.x + (size_t)b * T * C * HW + (size_t)(g * CPG) * HW + pix;
+    float* gxg = p.gx + (size_t)b * T * C * HW + (size_t)(g * CPG) * HW + pix;
+    const size_t hstride = (size_t)p.B * T * HW;
+
+    for (int tc0 = 0; tc0 < T; tc0 += GXT) {
+        __syncthreads();                           // r (first pass) or the previous chunk consumed
+        // stage attn and gs of GXT steps: 2 x GXT x 16 rows of 64 pixels, 32 rows per wave, 8 at a time
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = w * 32 + part * 8 + i;                  // 0 .. 511
+                const int arr = row >> 8, tt = (row >> 4) & 15, h = row & 15;
+                const int t = tc0 + tt < T ? tc0 + tt : T - 1;
+                const size_t o = (size_t)h * hstride + ((size_t)b * T + t) * HW + pix;
+                v[i] = arr == 0 ? p.attn_in[o] : p.GS[o];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = w * 32 + part * 8 + i;
+                const int arr = row >> 8, tt = (row >> 4) & 15, h = row & 15;
+                lds[(((arr * GXT + tt) * 4 + (h >> 2)) * 64 + lane) * 4 + (h & 3)] = v[i];
             }
         }
         __syncthreads();
-        const int tn = T - tc0 < SCB ? T - tc0 : SCB;
-        // x of 4 time steps ahead in registers; no barrier inside the chunk
-        float xn[4][2];
+        const int tn = T - tc0 < GXT ? T - tc0 : GXT;
+        float xn[2][CPG];
         auto issue = [&](int tt0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int t = tc0 + tt0 + u < T ? tc0 + tt0 + u : T - 1;
-                xn[u][0] = xg[(size_t)(t * C) * HW];
-                xn[u][1] = xg[(size_t)(t * C + 1) * HW];
+#pragma unroll
+                for (int cc = 0; cc < CPG; ++cc) xn[u][cc] = xg[(size_t)(t * C + cc) * HW];
             }
         };
         issue(0);
-        for (int tt0 = 0; tt0 < tn; tt0 += 4) {
-            float xv[4][2];
+        for (int tt0 = 0; tt0 < tn; tt0 += 2) {
+            float xv[2][CPG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { xv[u][0] = xn[u][0]; xv[u][1] = xn[u][1]; }
-            if (tt0 + 4 < tn) issue(tt0 + 4);
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                for (int cc = 0; cc < CPG; ++cc) xv[u][cc] = xn[u][cc];
+            if (tt0 + 2 < tn) issue(tt0 + 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
                 const int tt = tt0 + u, t = tc0 + tt;
                 if (tt < tn) {
-                    float d0 = 0.f, d1 = 0.f;
+                    float acc[CPG] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int hq = 0; hq < 4; ++hq) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(dchk + (((0 * SCB + tt) * 4 + hq) * SPT + px) * 4);
-                        const f32x4 gs = *reinterpret_cast<const f32x4*>(dchk + (((1 * SCB + tt) * 4 + hq) * SPT + px) * 4);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(lds + (((0 * GXT + tt) * 4 + hq) * 64 + lane) * 4);
+                        const f32x4 gs = *reinterpret_cast<const f32x4*>(lds + (((1 * GXT + tt) * 4 + hq) * 64 + lane) * 4);
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
                             const int h = hq * 4 + kk;
-                            d0 = fmaf(a[kk], r[h][0], d0); d0 = fmaf(gs[kk], u_[h][0], d0);
-                            d1 = fmaf(a[kk], r[h][1], d1); d1 = fmaf(gs[kk], u_[h][1], d1);
+#pragma unroll
+                            for (int cc = 0; cc < CPG; ++cc) {
+                                acc[cc] = fmaf(a[kk], r[h][cc], acc[cc]);
+                                acc[cc] = fmaf(gs[kk], ug[h][cc], acc[cc]);
+                            }
                         }
                     }
-                    if (act) {
-                        const float xn0 = (xv[u][0] - mean) * rstd, xn1 = (xv[u][1] - mean) * rstd;
-                        gxg[(size_t)(t * C) * HW] = gm0 * d0 - rstd * fmaf(xn0, m2, m1);
-                        gxg[(size_t)(t * C + 1) * HW] = gm1 * d1 - rstd * fmaf(xn1, m2, m1);
+#pragma unroll
+                    for (int cc = 0; cc < CPG; ++cc) {
+                        const float xnn = (xv[u][cc] - mean) * rstd;
+                        gxg[(size_t)(t * C + cc) * HW] = gm[cc] * acc[cc] - rstd * fmaf(xnn, m2, m1);
                     }
                 }
             }
@@ -2138,6 +2252,7 @@ void init_hook() {
     C2S_RAISE_LDS(ltae_bwd_gx_kernel);
     C2S_RAISE_LDS(ltae_stream_bwd_heads_kernel<4>);
     C2S_RAISE_LDS(ltae_stream_bwd_gx_kernel<4>);
+    C2S_RAISE_LDS(ltae_stream_bwd_gx64_kernel);
     C2S_RAISE_LDS(ltae_reg_fwd_kernel);
 }
 C2sInitRegistrar registrar(init_hook);
@@ -2261,9 +2376,13 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         const size_t lds1 = ((size_t)NH * d->C * SPT + NH * 2 * SPT + 2 * NH * SPT + 2 * SCH * 4 * SPT * 4 + (size_t)d->T * DV) * sizeof(float);
         hipLaunchKernelGGL(ltae_stream_bwd_heads_kernel<4>, dim3(tiles), dim3(1024), lds1, st, p, sb);
         C2S_CHECK_LAUNCH("ltae_stream_bwd_heads");
-        const size_t lds2 = (size_t)NH * d->C * SPT * sizeof(float);       // r, then the 32-step attn / gs chunk (same size)
-        static_assert(2 * SCB * 4 * SPT * 4 == NH * 64 * SPT, "deep chunk = r area");
-        hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), lds2, st, p, sb);
+        const size_t lds2 = ((size_t)NH * d->C * SPT + 2 * SCH * 4 * SPT * 4) * sizeof(float);
+        static const bool gx64 = [] { const char* e = getenv("C2S_LTAE_GX64"); return !(e && e[0] == '0'); }();
+        if (gx64 && d->C == 64 && d->HW % 64 == 0) {
+            hipLaunchKernelGGL(ltae_stream_bwd_gx64_kernel, dim3(d->B * (d->HW / 64)), dim3(1024), GX_FLOATS * sizeof(float), st, p, sb);
+        } else {
+            hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), lds2, st, p, sb);
+        }
         C2S_CHECK_LAUNCH("ltae_stream_bwd_gx");
     } else {
         hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
