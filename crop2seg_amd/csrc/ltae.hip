@@ -79,6 +79,14 @@ __device__ __forceinline__ float keep_scale(const LtaeParams& p, int h, long P_t
     return drop_pick(d, drop_bits(d, (long)h * P_total + pidx, t >> 1), t);
 }
 
+
+// XCD-aware tile order: workgroups go to the 8 XCDs round-robin, so XCD k gets the k-th contiguous eighth of the tiles (tiles that
+// share 128-byte lines sit behind the same L2).  (Visiting the eighth with a stride, so that the tiles running at the same time
+// are spread over the [HW] rows instead of a 2 KB window, changed nothing: 1.36 vs 1.37 ms forward, 4.17 vs 4.20 ms backward.)
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned grid) {
+    return (grid & 7) ? bid : (bid & 7) * (grid >> 3) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // Workgroup = 16 adjacent pixels.  Streaming phases use threads = (pixel quad q, slot) with float4 loads (4 pixels
 // per lane; 8-16 independent 16-byte loads in flight per thread keep >= 32 KB per CU outstanding), the per-pixel
@@ -1282,8 +1290,7 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
     // XCD-aware tile order: workgroups go to the 8 XCDs round-robin, so give each XCD a contiguous eighth of the tiles --
     // the two 16-pixel tiles that share every 128-byte line of x then sit behind the same L2.
     // (A persistent tile loop was tried: the loop-carried state pushed the kernel from 234 to 256 VGPRs + 65 spills, 1.39 -> 2.07 ms.)
-    unsigned tile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
     const int tiles_per_b = HW / RPX;
     const int b = (int)(tile / tiles_per_b);
     const int pix = (int)(tile % tiles_per_b) * RPX + px;
@@ -1624,6 +1631,7 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 struct StreamBwd {
     float* M;        // [P][16][2]  m1, m2
     float* part_U;   // [tiles][16][C]
+    float* gb64;     // [64-pixel tiles][C][2]  d gamma / d beta partials written by the dx kernel (NULL: the heads kernel wrote part_gb)
 };
 
 __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes of this half of the wave
@@ -2061,6 +2069,521 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, 
     }
 }
 
+// ------------------------------------------------------------------------------------------ register-resident backward, heads part
+// Backward of the attention block up to the dscores, in the layout of the register-resident forward (16-pixel tiles, lane =
+// (px, q), wave w owns time steps 8w..8w+7, xn[8 t][16 c] = the GroupNorm-normalised input without the affine part).  x is read
+// ONCE; the streaming heads kernel above reads it twice and re-reads r (128 KB of LDS) for every time step (its dots phase is
+// LDS-bound: 137k of its 414k cycles per 32-pixel tile).
+//
+//   H1 load x, statistics of the forward -> xn
+//   H2 r[h][c] = sum_j ge[16h+j] Wc[16h+j][c]            MFMA, two heads per wave; rows permuted so that lane (px, q) receives
+//                                                         its own 16 channels -> rL[h][px][c] (LDS)
+//   H3 dot[h][t] = sum_c r[h][c] xhat[t][c]              VALU on xn with r*gamma (+ sum_c r beta), 4 heads at a time, the four
+//                                                         channel quarters summed with two cross-lane exchanges
+//      c0[h][t] = ge_h . (bc_h + pe_t) + g_attn           ga = (dot + c0) * keep
+//   H4 gs = a (ga - sum_t a ga)                           softmax backward, one cross-wave exchange; gs -> GS (global, for the
+//                                                         dx kernel); d s0, d bc partials of the tile
+//   H5 Zt[h][c] = sum_t attn xn,  Vt[h][c] = sum_t gs xn  per pixel on the MFMA, xn staged through LDS as in the forward (F5),
+//                                                         one pass per weight array (the A operands of both do not fit)
+//   H6 closed forms per pixel from r, U, Zt, Vt           m1, m2 (GroupNorm-backward means), d gamma / d beta / d U partials,
+//                                                         Z = gamma Zt + beta sum_t attn -> global, transposed through LDS
+constexpr int RB_RP = 68;                          // rL pitch per (head, pixel): 64 c + 4
+constexpr int RB_A = 0;                            // aL [64 t][16 px][16 h] (pitch R_TP); before: exchange scratch + geL; between the passes: pU; later zT
+constexpr int RB_GE = RB_A + 4096;                 // geL [16 h][16 j][16 px] (head pitch RB_GH): the tile of g_emb, until aL is filled
+constexpr int RB_GH = 16 * 16 + 4;                 // = 4 mod 16: the four lane quarters (heads 4q + r) read 64 banks
+constexpr int RB_XS = RB_A + 16 * R_ZH;            // xs [16 px][16 t][64 c] (pitch R_XT / R_XP); before and after: rL [16 h][16 px][RB_RP], peL [T][16]
+constexpr int RB_AS = RB_XS + R_XB;                // asL [16 h][16 px]  sum_t attn;  before: bcL [256]
+constexpr int RB_FLOATS = RB_AS + 256;             // 38,272 floats = 153,088 bytes
+static_assert(R_XB >= 16 * 16 * RB_RP + 2048, "rL and peL / the H4 exchange fit the staging area");
+static_assert(RB_GE + 16 * RB_GH <= RB_XS && 8 * 1024 <= 16 * R_ZH, "geL / pU fit the aL area");
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
+__global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, StreamBwd sb) {
+    extern __shared__ float lds[];
+    float* aL = lds + RB_A;
+    float* red = lds + RB_XS + 16 * 16 * RB_RP;    // cross-wave exchange of H4 [8 w][16 h][16 px] (peL is dead by then)
+    float* geL = lds + RB_GE;
+    float* xs = lds + RB_XS;
+    float* rL = lds + RB_XS;
+    float* peL = lds + RB_XS + 16 * 16 * RB_RP;
+    float* asL = lds + RB_AS;
+    float* bcL = lds + RB_AS;
+    constexpr int C = 64;
+    const int T = p.T, HW = p.HW;
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);                              // XCD-aware order (partials: by tile)
+    const int tiles_per_b = HW / RPX;
+    const int b = (int)(tile / tiles_per_b);
+    const int pix0 = (int)(tile % tiles_per_b) * RPX, pix = pix0 + px;
+    const long pidx = (long)b * HW + pix;
+    const int t0 = 8 * w;
+    const int nt = T - t0 < 0 ? 0 : (T - t0 < 8 ? T - t0 : 8);
+    // Global addressing through buffer descriptors: a wave-uniform row offset in an SGPR + ONE per-lane byte offset per tensor.
+    // (Flat 64-bit per-lane addresses for the ~400 unrolled accesses of this kernel cost two registers per access in flight;
+    // the first version of this kernel carried 2.6 KB of scratch per lane and ran at 10.6 ms.)  The host checks the sizes < 2^31.
+    const unsigned rowb = (unsigned)HW * 4u;                                              // bytes per [HW] row
+    const unsigned abytes = 16u * (unsigned)(p.B * T) * rowb;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * T * C * HW), 0, (int)((unsigned)(T * C) * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rap = __builtin_amdgcn_make_buffer_rsrc((void*)p.attn_pre_in, 0, (int)abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)p.attn_in, 0, (int)abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rga = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g_attn != nullptr ? p.g_attn : p.attn_in), 0, (int)abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((void*)p.GS, 0, (int)abytes, 0x00020000);
+    const float gat_w = p.g_attn != nullptr ? 1.f : 0.f;   // no upstream gradient of the attention output: weight 0
+    const unsigned xvo = ((unsigned)(16 * q) * (unsigned)HW + (unsigned)pix) * 4u;
+    unsigned hvo[4];                               // attention tensors [16][B][T][HW]: head part + pixel
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hvo[r] = ((unsigned)(4 * q + r) * (unsigned)(p.B * T) * (unsigned)HW + (unsigned)pix) * 4u;
+    auto trow = [&](int i) {                       // byte offset of row (b, t0 + i), clamped to the last time step: an SGPR
+        const int tc = t0 + i < T ? t0 + i : T - 1;
+        return (unsigned)(b * T + tc) * rowb;
+    };
+    const float* geb = p.g_emb + (size_t)b * NH * DV * HW + pix0;                          // [256][HW] rows of the tile
+    const int chan = 16 * (px >> 2) + (px & 3);    // + 4 cb: the permuted MFMA rows of H2
+
+    // dropout scale (branch-free and up here: a basic-block boundary in the middle of the kernel lets LLVM sink the c0 sums of P0
+    // below the dots, with every operand spilled on the way)
+    const bool dropping = p.drop_p > 0.f;
+    const float thr16 = (float)(uint32_t)(p.drop_p * 65536.f + 0.5f);
+    const float kscale = !dropping ? 1.f : (p.keep != nullptr ? 1.f / (1.f - p.drop_p) : 65536.f / (65536.f - thr16));
+
+    LT_STAMP_B(0);
+    // ---- P0 .. H1, ordered for the load queue (a wave has 64 loads in flight at most and issues in order): the small operands
+    // first, then half of x, then -- while x streams -- the LDS fill, H2 and half of c0, the other half of x, the rest of c0.
+    // Small operands: the tile of g_emb, pe and bc (for LDS); upstream gradient of the attention output; Wc operands of H2.
+    float gav[8][4];
+    f32x4 gt[2];
+    float pev[2], wA[2][4][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 512 * k;             // (row, quarter of the 16 pixels)
+        gt[k] = *reinterpret_cast<const f32x4*>(geb + (size_t)(idx >> 2) * HW + 4 * (idx & 3));
+        pev[k] = idx < T * DV ? p.pe[(size_t)b * T * DV + idx] : 0.f;
+    }
+    const float bcv = tid < NH * DV ? p.bc[tid] : 0.f;
+    // H2 computes r of heads 2w, 2w+1.  MFMA rows are permuted: row i of channel block cb is channel 16 (i >> 2) + 4 cb + (i & 3), so
+    // that D (lane (px, q): rows 4q..4q+3) holds channels 16q + 4cb + r -- the lane's own.  A[i][k] = Wc[16h + 4s + k][chan(i)],
+    // B[k][n = px] = ge[16h + 4s + k][px].
+    auto load_wA = [&]() {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wA[hh][cb][s] = p.Wc[((2 * w + hh) * DV + 4 * s + q) * C + 4 * cb + chan];
+    };
+    auto r_mma = [&](const float (&gb)[2][4]) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[hh][cb][s], gb[hh][s], acc, 0, 0, 0);
+                *reinterpret_cast<f32x4*>(rL + ((2 * w + hh) * 16 + px) * RB_RP + 16 * q + 4 * cb) = acc;
+            }
+    };
+    load_wA();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gav[i][r] = gat_w * bload(rga, hvo[r], trow(i));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 x[8][8];
+    auto load_x = [&](int i) {
+        const int tc = t0 + i < T ? t0 + i : T - 1;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            x[i][s][0] = bload(rx, xvo, (unsigned)(tc * C + 2 * s) * rowb);
+            x[i][s][1] = bload(rx, xvo, (unsigned)(tc * C + 2 * s + 1) * rowb);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_x(i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 512 * k, row = idx >> 2;
+        *reinterpret_cast<f32x4*>(geL + (row >> 4) * RB_GH + (row & 15) * 16 + 4 * (idx & 3)) = gt[k];
+        if (idx < 64 * DV) peL[idx] = pev[k];
+    }
+    if (tid < NH * DV) bcL[tid] = bcv;
+    lds_barrier();                                 // geL, peL, bcL written
+    LT_STAMP_B(1);
+    {
+        float gb[2][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) gb[hh][s] = geL[(2 * w + hh) * RB_GH + (4 * s + q) * 16 + px];
+        r_mma(gb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LT_STAMP_B(2);
+    // c0[h][t] = ge_h . (bc_h + pe_t) + g_attn[h][t] for the lane's heads 4q..4q+3, all operands from LDS (no global load
+    // behind the x stream); the dots are added in H3
+    auto c0_head = [&](int r) {
+        const int h = 4 * q + r;
+        float gev[16];
+        float gebc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gev[j] = geL[h * RB_GH + j * 16 + px];
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const f32x4 bc4 = *reinterpret_cast<const f32x4*>(bcL + h * DV + 4 * jq);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) gebc = fmaf(gev[4 * jq + jj], bc4[jj], gebc);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tc = t0 + i < T ? t0 + i : T - 1;
+            float c0 = gav[i][r] + gebc;
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(peL + tc * DV + 4 * jq);
+                c0 = fmaf(gev[4 * jq + 0], pv[0], c0); c0 = fmaf(gev[4 * jq + 1], pv[1], c0);
+                c0 = fmaf(gev[4 * jq + 2], pv[2], c0); c0 = fmaf(gev[4 * jq + 3], pv[3], c0);
+            }
+            asm volatile("" : "+v"(c0));           // computed HERE (see the note on code sinking at kscale)
+            gav[i][r] = c0;
+        }
+    };
+    c0_head(0);
+    __builtin_amdgcn_sched_barrier(0);
+    c0_head(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // the other half of x; the statistics of the forward behind it
+#pragma unroll
+    for (int i = 4; i < 8; ++i) load_x(i);
+    float na[16], nc[16];                          // xhat = x * na + nc  (na = rstd gamma, nc = beta - mean rstd gamma)
+    {
+        const f32x4 st0 = *reinterpret_cast<const f32x4*>(p.stats_in + (pidx * NH + 4 * q) * 2);
+        const f32x4 st1 = *reinterpret_cast<const f32x4*>(p.stats_in + (pidx * NH + 4 * q) * 2 + 4);
+        const float mean[4] = {st0[0], st0[2], st1[0], st1[2]}, rs[4] = {st0[1], st0[3], st1[1], st1[3]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + 16 * q + 4 * u);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + 16 * q + 4 * u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                na[4 * u + e] = rs[u] * g4[e];
+                nc[4 * u + e] = fmaf(-mean[u], na[4 * u + e], b4[e]);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    c0_head(2);
+    __builtin_amdgcn_sched_barrier(0);
+    c0_head(3);
+    __builtin_amdgcn_sched_barrier(0);
+    LT_STAMP_B(3);
+    // xhat = gamma xn + beta in registers: the dots, Z = sum_t attn xhat (for d Wc) and V = sum_t gs xhat (= d U) need no further
+    // gamma / beta; the GroupNorm-backward means follow from Z, V, r, U in closed form (H6); d gamma / d beta come from the dx kernel
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            x[i][s][0] = i < nt ? fmaf(x[i][s][0], na[2 * s], nc[2 * s]) : 0.f;            // steps T..63: zero
+            x[i][s][1] = i < nt ? fmaf(x[i][s][1], na[2 * s + 1], nc[2 * s + 1]) : 0.f;
+        }
+    lds_barrier();                                 // rL complete; geL, peL, bcL consumed
+    LT_STAMP_B(4);
+    // ---- H3: dots dot[h][t] = sum_c r[h][c] xhat[t][c].  Every lane sums its 16 channels for all 16 heads (packed FMAs); the sum
+    // over the four channel quarters is a reduce-scatter: head h = 4Q + j belongs to lane quarter Q, so for a given j the four
+    // partials of a lane go to the four quarters -- one exchange across the wave halves (Q >> 1), one across the quarter pairs.
+    {
+        const bool Hh = (q >> 1) != 0, Pp = (q & 1) != 0;
+        auto head_dot = [&](int h, float (&out)[8]) {
+            f32x2 rv[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rL + (h * 16 + px) * RB_RP + 16 * q + 4 * u);
+                rv[2 * u] = (f32x2){v[0], v[1]}; rv[2 * u + 1] = (f32x2){v[2], v[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_elementwise_fma(rv[s], x[i][s], acc);
+                out[i] = acc[0] + acc[1];
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float keepA[8], keepB[8];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float dlo[8], dhi[8];
+                __builtin_amdgcn_sched_barrier(0);
+                head_dot(4 * pr + j, dlo);         // owner quarter Q = pr      (lower half of the wave)
+                __builtin_amdgcn_sched_barrier(0);
+                head_dot(4 * (pr + 2) + j, dhi);   // owner quarter Q = pr + 2  (upper half)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float send = Hh ? dlo[i] : dhi[i], mine = Hh ? dhi[i] : dlo[i];
+                    float v = mine + __shfl_xor(send, 32, 64);
+                    asm volatile("" : "+v"(v));    // the exchange happens HERE: left alone, instruction selection defers all 96
+                                                   // of them to the end of H3, with every partial sum kept (and spilled)
+                    if (pr == 0) keepA[i] = v; else keepB[i] = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {          // keepA: quarter 2H, keepB: quarter 2H + 1
+                const float send = Pp ? keepA[i] : keepB[i], mine = Pp ? keepB[i] : keepA[i];
+                float v = gav[i][j] + (mine + __shfl_xor(send, 16, 64));
+                asm volatile("" : "+v"(v));
+                gav[i][j] = v;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LT_STAMP_B(5);
+    // ---- H4: ga = (dot + c0) * keep; softmax backward gs = a (ga - sum_t a ga): one exchange over the 8 waves.
+    // keep is read off the stored weights (attn = attn_pre * keep: no RNG here); where attn_pre = 0 the value of ga is irrelevant.
+    // attn_pre stays in registers until gs is formed, attn goes straight into aL for the Z pass: every tensor is read once.
+    {
+        float apk[8][4], sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            __builtin_amdgcn_sched_barrier(0);
+            float adv[4][4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    apk[4 * ih + ii][r] = bload(rap, hvo[r], trow(4 * ih + ii));
+                    adv[ii][r] = bload(rad, hvo[r], trow(4 * ih + ii));
+                }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * ih + ii;
+                const float live = i < nt ? 1.f : 0.f;             // steps T..63 carry no weight (their loads repeat row T-1)
+                f32x4 at;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (arithmetic masks, not selects of the loaded values: a load that is only needed when i < nt becomes a
+                    // branch, and a basic-block boundary here lets LLVM sink the c0 sums below the dots)
+                    const float ks = ((dropping && adv[ii][r] == 0.f) ? 0.f : kscale) * live;
+                    const float ga = gav[i][r] * ks;
+                    gav[i][r] = ga;
+                    sm[r] = fmaf(apk[i][r], ga, sm[r]);
+                    at[r] = adv[ii][r] * live;
+                }
+                *reinterpret_cast<f32x4*>(aL + (t0 + i) * R_TP + px * 16 + 4 * q) = at;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(w * 16 + 4 * q + r) * 16 + px] = sm[r];
+        lds_barrier();                             // also: aL (attn) complete
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) s += red[(ww * 16 + 4 * q + r) * 16 + px];
+            sm[r] = s;
+        }
+        lds_barrier();                             // the exchange area is part of xs: read by all waves before the first chunk is staged
+        // gs (in place of ga), GS rows to global (for the dx kernel)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gs = i < nt ? apk[i][r] * (gav[i][r] - sm[r]) : 0.f;
+                gav[i][r] = gs;
+                bstore(gs, rgs, i < nt ? hvo[r] : 0x80000000u, trow(i));        // steps T..63: out of range, dropped by the range check
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    LT_STAMP_B(6);
+    // ---- H5: per-pixel MFMA products with xhat staged through LDS (see F5 of the forward): D[h][c] = sum_t w[h][t] xhat[t][c],
+    // lane (n = hl, q): head 4q + r, channel 16 cb + n, pixels 2w + u.  Z pass (weights attn, already in aL) first, then the V pass
+    // (weights gs): the accumulators of both do not fit beside x, so everything that needs Z is done between the passes.
+    const int hl = px;
+    const float* ap0 = aL + q * R_TP + (2 * w) * 16 + hl;
+    const float* bp0 = xs + (2 * w) * R_XP + q * R_XT + hl;
+    f32x4 acc[4][2];
+    auto weighted_sums = [&](bool vpass) {
+        if (vpass) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(aL + (t0 + i) * R_TP + px * 16 + 4 * q) = (f32x4){gav[i][0], gav[i][1], gav[i][2], gav[i][3]};
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) { acc[cb][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[cb][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            if ((w >> 1) == tq) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        *reinterpret_cast<f32x4*>(xs + px * R_XP + (8 * (w & 1) + i) * R_XT + 16 * q + 4 * u) =
+                            (f32x4){x[i][2 * u][0], x[i][2 * u][1], x[i][2 * u + 1][0], x[i][2 * u + 1][1]};
+            }
+            lds_barrier();
+            float av[2][4], bv[2][4][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    av[u][s] = ap0[(16 * tq + 4 * s) * R_TP + 16 * u];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) bv[u][cb][s] = bp0[4 * s * R_XT + 16 * cb + R_XP * u];
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[cb][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], bv[u][cb][s], acc[cb][u], 0, 0, 0);
+            if (tq == 3) {
+                if (vpass) {
+                    // d s0[t][h] partial = sum over the 16 pixels of gs: thread = (t, h), two each
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int o = tid + 512 * k, t = o >> 4;
+                        float v = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v += aL[t * R_TP + e * 16 + (o & 15)];
+                        if (t < T) p.part_s0[(size_t)tile * T * NH + o] = v;
+                    }
+                } else if (tid < 256) {
+                    // asum[h][px] = sum_t attn: thread = (px, h)
+                    float v = 0.f;
+#pragma unroll 16
+                    for (int t = 0; t < 64; ++t) v += aL[t * R_TP + tid];
+                    asL[(tid & 15) * 16 + (tid >> 4)] = v;
+                }
+            }
+            lds_barrier();
+        }
+    };
+    weighted_sums(false);                          // Zt
+    // ---- H6a: r again (the staging area is free), then everything that needs Z, in the D layout of H5:
+    // lane (n = hl, q): head h = 4q + r, channel c = 16 cb + n, pixel pu = 2w + u;  Z, V are the xhat-based sums.
+    //   m1_g = 1/n sum_{c in g} gamma_c sum_h asum_h r[h][c]
+    //   m2_g = 1/n sum_{c in g} sum_h (r[h][c] (Z[h][c] - beta_c asum_h) + U[h][c] V[h][c])      (sum_t gs = 0)
+    {
+        float gb[2][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) gb[hh][s] = geb[(size_t)((2 * w + hh) * DV + 4 * s + q) * HW + px];
+        load_wA();
+        r_mma(gb);
+    }
+    lds_barrier();
+    const float inv_n = 1.f / (float)(4 * T);
+    float g2z[4][2];
+    {
+        float as_[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) as_[r][u] = asL[(4 * q + r) * 16 + 2 * w + u];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int c = 16 * cb + hl;
+            const float gmc = p.gamma[c], btc = p.beta[c];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pu = 2 * w + u;
+                float g2 = 0.f, g1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rr = rL[((4 * q + r) * 16 + pu) * RB_RP + c];
+                    g2 = fmaf(rr, acc[cb][u][r] - btc * as_[r][u], g2);
+                    g1 = fmaf(rr, as_[r][u], g1);
+                }
+                asm volatile("" : "+v"(g2));
+                g2z[cb][u] = g2;
+                float m1 = gmc * g1;
+                // all 16 heads (the four lane quarters) and the 4 channels of group 4 cb + (hl >> 2) (4 adjacent lanes)
+                m1 += __shfl_xor(m1, 16, 64); m1 += __shfl_xor(m1, 32, 64); m1 += __shfl_xor(m1, 1, 64); m1 += __shfl_xor(m1, 2, 64);
+                if (q == 0 && (hl & 3) == 0) sb.M[(((long)b * HW + pix0 + pu) * NH + 4 * cb + (hl >> 2)) * 2] = m1 * inv_n;
+            }
+        }
+        // Z[h][c][px] transposed through LDS for 64-byte row stores (aL is dead since the last barrier of the Z pass)
+        float* zT = lds + RB_A;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zT[(4 * q + r) * R_ZH + (16 * cb + hl) * RZP + 2 * w + u] = acc[cb][u][r];
+        lds_barrier();
+        float* zrow = p.Z + (size_t)b * NH * C * HW + pix0 + (tid & 15);
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int row = (tid >> 4) + 32 * kk;  // (h, c)
+            zrow[(size_t)row * HW] = zT[(row >> 6) * R_ZH + (row & 63) * RZP + (tid & 15)];
+        }
+        lds_barrier();                             // zT consumed: the area becomes aL again; rL is dead (xs takes its place)
+    }
+    weighted_sums(true);                           // Vt
+    // x is dead from here on
+    // ---- H6b: d U partial of the tile through LDS, the V part of m2, d bc partial
+    {
+        float* pU = lds + RB_A;                    // [8 w][16 (cb, r)][64 lanes]
+        f32x4 gd[4];
+        if (tid < NH * DV) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gd[k] = *reinterpret_cast<const f32x4*>(geb + (size_t)tid * HW + 4 * k);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            float uv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) uv[r] = p.U[(4 * q + r) * C + 16 * cb + hl];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float m2 = g2z[cb][u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m2 = fmaf(uv[r], acc[cb][u][r], m2);
+                m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64); m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64);
+                if (q == 0 && (hl & 3) == 0) sb.M[(((long)b * HW + pix0 + 2 * w + u) * NH + 4 * cb + (hl >> 2)) * 2 + 1] = m2 * inv_n;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pU[(w * 16 + cb * 4 + r) * 64 + lane] = acc[cb][0][r] + acc[cb][1][r];
+        }
+        // d bc[16h+j] partial = sum_px ge[16h+j][px] sum_t attn[h][px]: thread = (h, j), its row of the tile is 64 contiguous bytes
+        if (tid < NH * DV) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(asL + (tid >> 4) * 16 + 4 * k);
+                v = fmaf(gd[k][0], a4[0], v); v = fmaf(gd[k][1], a4[1], v); v = fmaf(gd[k][2], a4[2], v); v = fmaf(gd[k][3], a4[3], v);
+            }
+            p.part_bc[(size_t)tile * NH * DV + tid] = v;
+        }
+        lds_barrier();
+        // tile partial of d U [16 h][64 c] (2 per thread), fixed order over the waves
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int o = tid + 512 * kk;          // o = (cb * 4 + r) * 64 + lane'  with lane' = q' * 16 + n
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) sum += pU[ww * 1024 + o];
+            const int cbr = o >> 6, ln = o & 63;
+            const int h = 4 * (ln >> 4) + (cbr & 3), c = 16 * (cbr >> 2) + (ln & 15);
+            sb.part_U[((size_t)tile * NH + h) * C + c] = sum;
+        }
+    }
+    LT_STAMP_B(7);
+}
+
 // ------------------------------------------------------------------------------------------ gx kernel, 64-pixel tiles
 // d x of the streaming backward with the lane = pixel / wave = GroupNorm group layout of the streaming forward:
 //   gx[t][c] = rstd (gamma_c sum_h (attn[h,t] r[h][c] + gs[h,t] U[h][c]) - m1 - xn[t][c] m2)
@@ -2077,8 +2600,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
     const int T = p.T, HW = p.HW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned tile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);          // XCD-aware order
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);                              // XCD-aware order
     const int tiles_per_b = HW / 64;
     const int b = (int)(tile / tiles_per_b);
     const int pix = (int)(tile % tiles_per_b) * 64 + lane;
@@ -2145,6 +2667,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
     const float* xg = p.x + (size_t)b * T * C * HW + (size_t)(g * CPG) * HW + pix;
     float* gxg = p.gx + (size_t)b * T * C * HW + (size_t)(g * CPG) * HW + pix;
     const size_t hstride = (size_t)p.B * T * HW;
+    float dgam[CPG] = {0.f, 0.f, 0.f, 0.f}, dbet[CPG] = {0.f, 0.f, 0.f, 0.f};     // sum_t d xhat * xn, sum_t d xhat (this pixel)
 
     for (int tc0 = 0; tc0 < T; tc0 += GXT) {
         __syncthreads();                           // r (first pass) or the previous chunk consumed
@@ -2209,8 +2732,21 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
                     for (int cc = 0; cc < CPG; ++cc) {
                         const float xnn = (xv[u][cc] - mean) * rstd;
                         gxg[(size_t)(t * C + cc) * HW] = gm[cc] * acc[cc] - rstd * fmaf(xnn, m2, m1);
+                        dgam[cc] = fmaf(acc[cc], xnn, dgam[cc]);
+                        dbet[cc] += acc[cc];
                     }
                 }
+            }
+        }
+    }
+    // d gamma / d beta partials of the tile (sum over its 64 pixels) when the heads kernel leaves them to this one
+    if (sb.gb64 != nullptr) {
+#pragma unroll
+        for (int cc = 0; cc < CPG; ++cc) {
+            const float sg = wave_sum(dgam[cc]), sbt = wave_sum(dbet[cc]);
+            if (lane == 0) {
+                sb.gb64[((size_t)tile * C + g * CPG + cc) * 2 + 0] = sg;
+                sb.gb64[((size_t)tile * C + g * CPG + cc) * 2 + 1] = sbt;
             }
         }
     }
@@ -2253,6 +2789,7 @@ void init_hook() {
     C2S_RAISE_LDS(ltae_stream_bwd_heads_kernel<4>);
     C2S_RAISE_LDS(ltae_stream_bwd_gx_kernel<4>);
     C2S_RAISE_LDS(ltae_stream_bwd_gx64_kernel);
+    C2S_RAISE_LDS(ltae_reg_bwd_heads_kernel);
     C2S_RAISE_LDS(ltae_reg_fwd_kernel);
 }
 C2sInitRegistrar registrar(init_hook);
@@ -2353,7 +2890,11 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     C2S_REQUIRE(ws_floats >= c2s_ltae_bwd_workspace_floats(d), "ltae_bwd: workspace too small");
     (void)s0; (void)valid;
     const bool stream_path = g_emb != nullptr && use_stream(d);
-    const int PT = stream_path ? SPT : bwd_pt(d);
+    static const bool reg_bwd_on = [] { const char* e = getenv("C2S_LTAE_REG_BWD"); return !(e && e[0] == '0'); }();
+    // register-resident heads kernel + 64-px dx kernel; its buffer descriptors address < 2^31 bytes per tensor
+    const bool reg_heads = stream_path && reg_bwd_on && use_reg_fwd(d) && d->HW % 64 == 0 &&
+                           (size_t)16 * d->B * d->T * d->HW < ((size_t)1 << 29) && (size_t)d->T * d->C * d->HW < ((size_t)1 << 29);
+    const int PT = reg_heads ? RPX : (stream_path ? SPT : bwd_pt(d));
     const size_t tiles = (size_t)d->B * ((d->HW + PT - 1) / PT);
     const size_t tiles_ws = (size_t)d->B * ((d->HW + 7) / 8);
     LtaeParams p = {};
@@ -2374,11 +2915,16 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         sb.M = p.V;
         sb.part_U = p.V + (size_t)d->B * d->HW * NH * 2;
         const size_t lds1 = ((size_t)NH * d->C * SPT + NH * 2 * SPT + 2 * NH * SPT + 2 * SCH * 4 * SPT * 4 + (size_t)d->T * DV) * sizeof(float);
-        hipLaunchKernelGGL(ltae_stream_bwd_heads_kernel<4>, dim3(tiles), dim3(1024), lds1, st, p, sb);
+        if (reg_heads) {
+            sb.gb64 = p.part_gb;                   // d gamma / d beta partials come from the dx kernel, one per 64-pixel tile
+            hipLaunchKernelGGL(ltae_reg_bwd_heads_kernel, dim3(tiles), dim3(512), RB_FLOATS * sizeof(float), st, p, sb);
+        } else {
+            hipLaunchKernelGGL(ltae_stream_bwd_heads_kernel<4>, dim3(tiles), dim3(1024), lds1, st, p, sb);
+        }
         C2S_CHECK_LAUNCH("ltae_stream_bwd_heads");
         const size_t lds2 = ((size_t)NH * d->C * SPT + 2 * SCH * 4 * SPT * 4) * sizeof(float);
         static const bool gx64 = [] { const char* e = getenv("C2S_LTAE_GX64"); return !(e && e[0] == '0'); }();
-        if (gx64 && d->C == 64 && d->HW % 64 == 0) {
+        if ((gx64 || reg_heads) && d->C == 64 && d->HW % 64 == 0) {
             hipLaunchKernelGGL(ltae_stream_bwd_gx64_kernel, dim3(d->B * (d->HW / 64)), dim3(1024), GX_FLOATS * sizeof(float), st, p, sb);
         } else {
             hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), lds2, st, p, sb);
@@ -2402,7 +2948,8 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     C2S_CHECK_LAUNCH("ltae_reduce_bc");
     {   // interleaved (dgamma, dbeta) -> two outputs: reduce into a [C][2] scratch then split (reuse part_bc tail)
         float* gb = p.part_bc;   // part_bc is consumed above; 2*C <= 256 floats fit in its first entries
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * d->C), dim3(64), 0, st, p.part_gb, gb, (int)tiles,
+        const int gb_tiles = reg_heads ? d->B * (d->HW / 64) : (int)tiles;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * d->C), dim3(64), 0, st, p.part_gb, gb, gb_tiles,
                            2 * d->C, (long)2 * d->C);
         C2S_CHECK_LAUNCH("ltae_reduce_gb");
         hipMemcpy2DAsync(ggamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
