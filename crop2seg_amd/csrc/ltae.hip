@@ -2139,12 +2139,12 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
     const __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((void*)p.GS, 0, (int)abytes, 0x00020000);
     const float gat_w = p.g_attn != nullptr ? 1.f : 0.f;   // no upstream gradient of the attention output: weight 0
     const unsigned xvo = ((unsigned)(16 * q) * (unsigned)HW + (unsigned)pix) * 4u;
-    unsigned hvo[4];                               // attention tensors [16][B][T][HW]: head part + pixel
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hvo[r] = ((unsigned)(4 * q + r) * (unsigned)(p.B * T) * (unsigned)HW + (unsigned)pix) * 4u;
-    auto trow = [&](int i) {                       // byte offset of row (b, t0 + i), clamped to the last time step: an SGPR
+    // attention tensors [16][B][T][HW]: per-lane offset of head 4q + pixel; head 4q + r and the row (b, t) go into the SGPR offset
+    const unsigned headb = (unsigned)(p.B * T) * rowb;
+    const unsigned hv0 = (unsigned)(4 * q) * headb + (unsigned)pix * 4u;
+    auto trow = [&](int i, int r) {                // byte offset of head r, row (b, t0 + i) clamped to the last time step: an SGPR
         const int tc = t0 + i < T ? t0 + i : T - 1;
-        return (unsigned)(b * T + tc) * rowb;
+        return (unsigned)(b * T + tc) * rowb + (unsigned)r * headb;
     };
     const float* geb = p.g_emb + (size_t)b * NH * DV * HW + pix0;                          // [256][HW] rows of the tile
     const int chan = 16 * (px >> 2) + (px & 3);    // + 4 cb: the permuted MFMA rows of H2
@@ -2195,7 +2195,7 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gav[i][r] = gat_w * bload(rga, hvo[r], trow(i));
+        for (int r = 0; r < 4; ++r) gav[i][r] = gat_w * bload(rga, hv0, trow(i, r));
     __builtin_amdgcn_sched_barrier(0);
     f32x2 x[8][8];
     auto load_x = [&](int i) {
@@ -2260,9 +2260,14 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
     __builtin_amdgcn_sched_barrier(0);
     c0_head(1);
     __builtin_amdgcn_sched_barrier(0);
-    // the other half of x; the statistics of the forward behind it
+    // the other half of x
 #pragma unroll
     for (int i = 4; i < 8; ++i) load_x(i);
+    __builtin_amdgcn_sched_barrier(0);
+    c0_head(2);
+    __builtin_amdgcn_sched_barrier(0);
+    c0_head(3);
+    __builtin_amdgcn_sched_barrier(0);
     float na[16], nc[16];                          // xhat = x * na + nc  (na = rstd gamma, nc = beta - mean rstd gamma)
     {
         const f32x4 st0 = *reinterpret_cast<const f32x4*>(p.stats_in + (pidx * NH + 4 * q) * 2);
@@ -2279,10 +2284,6 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
             }
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    c0_head(2);
-    __builtin_amdgcn_sched_barrier(0);
-    c0_head(3);
     __builtin_amdgcn_sched_barrier(0);
     LT_STAMP_B(3);
     // xhat = gamma xn + beta in registers: the dots, Z = sum_t attn xhat (for d Wc) and V = sum_t gs xhat (= d U) need no further
@@ -2360,8 +2361,8 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
             for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    apk[4 * ih + ii][r] = bload(rap, hvo[r], trow(4 * ih + ii));
-                    adv[ii][r] = bload(rad, hvo[r], trow(4 * ih + ii));
+                    apk[4 * ih + ii][r] = bload(rap, hv0, trow(4 * ih + ii, r));
+                    adv[ii][r] = bload(rad, hv0, trow(4 * ih + ii, r));
                 }
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
@@ -2400,7 +2401,7 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
             for (int r = 0; r < 4; ++r) {
                 const float gs = i < nt ? apk[i][r] * (gav[i][r] - sm[r]) : 0.f;
                 gav[i][r] = gs;
-                bstore(gs, rgs, i < nt ? hvo[r] : 0x80000000u, trow(i));        // steps T..63: out of range, dropped by the range check
+                bstore(gs, rgs, i < nt ? hv0 : 0x80000000u, trow(i, r));        // steps T..63: out of range, dropped by the range check
             }
     }
     __builtin_amdgcn_sched_barrier(0);
