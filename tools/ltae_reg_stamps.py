@@ -30,10 +30,27 @@ sd = {k: v.to(dev) for k, v in seeded.make_state(ks, 21, "tame").items()}
 x = torch.randn(Bn, T, Cc, h, h, device=dev)
 dates = (5 * torch.arange(T, device=dev)[None]).repeat(Bn, 1)
 valid = torch.ones(Bn * T, dtype=torch.int32, device=dev)
+# C2S_CU_MASK=half: run on a stream restricted to every other CU (hipExtStreamCreateWithCUMask) -- if the load phases get
+# shorter per tile, they are bound by the memory system as a whole; if not, by what one CU can request
+stream_ctx = None
+if os.environ.get("C2S_CU_MASK") == "half":
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    mask = (C.c_uint32 * 8)(*([0x55555555] * 8))
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask) == 0
+    stream_ctx = torch.cuda.stream(torch.cuda.ExternalStream(st.value))
+    stream_ctx.__enter__()
+    print("running on a CU-masked stream (every other CU)")
 for _ in range(2):
     ctx = E.Ctx(sd, {}, {k: torch.empty_like(v) for k, v in sd.items()}, E.Workspace(dev), True, None)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
     emb, attn = E.ltae_attention(ctx, x, dates, valid, "te", 16, 4, 256, 1000.0, 0.1, True, 1234, None)
+    t1.record()
 torch.cuda.synchronize()
+print(f"forward call: {t0.elapsed_time(t1):.3f} ms")
+if stream_ctx is not None:
+    stream_ctx.__exit__(None, None, None)
 lib = E.lib()
 buf = np.zeros(4096 * 8, dtype=np.uint64)
 lib.c2s_debug_ltae_stamps.argtypes = [C.c_void_p]
