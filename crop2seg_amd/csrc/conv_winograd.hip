@@ -38,7 +38,7 @@ struct WinoParams {
 
 constexpr int WN_CK = 8;
 constexpr int WN_USLAB = 16 * WN_CK * 64;          // floats of one U chunk
-constexpr int WN_EXCH = 4 * 2 * 16 * 64;           // floats of the epilogue exchange [xi][x][r][lane] (one 32-channel half)
+constexpr int WN_EXCH = 4 * 2 * 16 * 64;           // floats of the epilogue exchange [xi][x][row group][lane][4 rows] (one 32-channel half)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -328,17 +328,31 @@ __global__ __launch_bounds__(256, 2) void conv_winograd_kernel(WinoParams p) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             if (m == 1) lds_barrier();                // first half fully read
+            // exchange layout [xi 4][x 2][row group 4][lane 64][4 rows]: one 16-byte write per (x, row group) and one 16-byte
+            // read per (xi, x) of the row group a wave finishes (a quarter of the LDS instructions of a [..][r][lane] layout)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
-                ex[((xi * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
-                ex[((xi * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+            for (int rg = 0; rg < 4; ++rg) {
+                f32x4 p0, p1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rg + e;
+                    const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
+                    p0[e] = m0 + m1 + m2;
+                    p1[e] = m1 - m2 - m3;
+                }
+                *reinterpret_cast<f32x4*>(ex + ((xi * 2 + 0) * 4 + rg) * 256 + lane * 4) = p0;
+                *reinterpret_cast<f32x4*>(ex + ((xi * 2 + 1) * 4 + rg) * 256 + lane * 4) = p1;
             }
             lds_barrier();
             if (m == 0) WN_STAMP(5); else WN_STAMP(7);
             // xi side: Y[0][x] = P0 + P1 + P2, Y[1][x] = P1 - P2 - P3; wave w finishes accumulator rows r with r>>2 == w.
             // Neighbouring lanes (blocks bx, bx+1) swap one row each so that every lane stores ONE float4 (4 pixels of
             // a row): even lanes write row 0 of both blocks, odd lanes row 1.
+            f32x4 Pq[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) Pq[q][x] = *reinterpret_cast<const f32x4*>(ex + ((q * 2 + x) * 4 + xi) * 256 + lane * 4);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = xi * 4 + rr;
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_winograd_kernel(WinoParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int x = 0; x < 2; ++x) P[q][x] = ex[((q * 2 + x) * 16 + r) * 64 + lane];
+                    for (int x = 0; x < 2; ++x) P[q][x] = Pq[q][x][rr];
                 const float y00 = P[0][0] + P[1][0] + P[2][0], y01 = P[0][1] + P[1][1] + P[2][1];
                 const float y10 = P[1][0] - P[2][0] - P[3][0], y11 = P[1][1] - P[2][1] - P[3][1];
                 // send the row the partner stores, receive the partner's share of the row this lane stores
