@@ -227,6 +227,11 @@ def _ltae_state(C, g, flavour="tame"):
     # every T-chunk loop iterated several times and the T-dependent dynamic LDS of the backward at its maximum
     (2, 61, 64, 128, True, True, True),
     (2, 61, 64, 128, True, False, False),
+    # edges of the register-resident kernels (wave w owns time steps 8w .. 8w+7): the maximum T = 64 at exactly 4 tiles per CU,
+    # a partly filled second wave, and a single time step (seven of the eight waves carry no step at all)
+    (1, 64, 64, 128, True, True, True),
+    (2, 9, 64, 128, True, True, True),
+    (2, 1, 64, 128, True, False, True),
 ])
 def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     E, L = _engine()
