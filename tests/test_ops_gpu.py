@@ -232,6 +232,7 @@ def _ltae_state(C, g, flavour="tame"):
     (1, 64, 64, 128, True, True, True),
     (2, 9, 64, 128, True, True, True),
     (2, 1, 64, 128, True, False, True),
+    (4, 7, 64, 64, True, True, True),       # 64x64 planes: 256 tiles per batch element, exactly 4 tiles per CU
 ])
 def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     E, L = _engine()
