@@ -232,3 +232,29 @@ def test_padded_frames_give_pad_value_features():
         x0 = x[:1].contiguous()
         g0 = Fn.conv_block(ctx, x0.view(T, 10, H, H), "in_conv", 2, "group", spec, None, need_input_grad=False)
         assert torch.equal(g0, f0[:T])
+
+
+def test_c5_shape_hipgraph_replay_equals_eager():
+    """BASELINE.json configs[4] runs the step as a captured hipGraph at 256x256, T = 48: at that plane size (B = 2 here, 8 per
+    GPU there -- same kernels) the replayed step is bit-identical to eager launches (dropout off so the masks coincide)."""
+    C2S, L, E, Fn, LU, synthetic_batch = _mods()
+    x, dates, y, _ = synthetic_batch(2, 48, 256, 256, 3, "cuda", irregular=False, lengths=[48, 40])
+
+    def fresh():
+        net = _model("utae", seed=5).train()
+        net.spec.attn_dropout = 0.0
+        net.spec.mlp_dropout = 0.0
+        return net, LU.TrainStep(net, num_classes=15)
+
+    net_e, step_e = fresh()
+    for _ in range(3):
+        loss_e, _ = step_e(x, dates, y)
+    net_g, step_g = fresh()
+    step_g(x, dates, y)
+    step_g.capture(x, dates, y)
+    for _ in range(2):
+        loss_g, _ = step_g.replay()
+    torch.cuda.synchronize()
+    assert float(loss_g) == float(loss_e) and float(loss_e) == float(loss_e)
+    assert torch.equal(step_g.flat_param, step_e.flat_param)
+    assert int(step_g.step_dev) == 3
