@@ -2071,22 +2071,24 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx_kernel(LtaeParams p, 
 
 // ------------------------------------------------------------------------------------------ register-resident backward, heads part
 // Backward of the attention block up to the dscores, in the layout of the register-resident forward (16-pixel tiles, lane =
-// (px, q), wave w owns time steps 8w..8w+7, xn[8 t][16 c] = the GroupNorm-normalised input without the affine part).  x is read
-// ONCE; the streaming heads kernel above reads it twice and re-reads r (128 KB of LDS) for every time step (its dots phase is
-// LDS-bound: 137k of its 414k cycles per 32-pixel tile).
+// (px, q), wave w owns time steps 8w..8w+7, xhat[8 t][16 c] = the GroupNorm output in registers).  Every tensor is read ONCE;
+// the streaming heads kernel above reads x twice and re-reads r (128 KB of LDS) for every time step (its dots phase is
+// LDS-bound: 137k of its 414k cycles per 32-pixel tile).  Phases, in program order:
 //
-//   H1 load x, statistics of the forward -> xn
-//   H2 r[h][c] = sum_j ge[16h+j] Wc[16h+j][c]            MFMA, two heads per wave; rows permuted so that lane (px, q) receives
+//   P0  small operands: tile of g_emb, pe, bc -> LDS; g_attn -> ga; Wc operands; the first half of x is requested here
+//   H2  r[h][c] = sum_j ge[16h+j] Wc[16h+j][c]           MFMA, two heads per wave; rows permuted so that lane (px, q) receives
 //                                                         its own 16 channels -> rL[h][px][c] (LDS)
-//   H3 dot[h][t] = sum_c r[h][c] xhat[t][c]              VALU on xn with r*gamma (+ sum_c r beta), 4 heads at a time, the four
-//                                                         channel quarters summed with two cross-lane exchanges
-//      c0[h][t] = ge_h . (bc_h + pe_t) + g_attn           ga = (dot + c0) * keep
-//   H4 gs = a (ga - sum_t a ga)                           softmax backward, one cross-wave exchange; gs -> GS (global, for the
-//                                                         dx kernel); d s0, d bc partials of the tile
-//   H5 Zt[h][c] = sum_t attn xn,  Vt[h][c] = sum_t gs xn  per pixel on the MFMA, xn staged through LDS as in the forward (F5),
-//                                                         one pass per weight array (the A operands of both do not fit)
-//   H6 closed forms per pixel from r, U, Zt, Vt           m1, m2 (GroupNorm-backward means), d gamma / d beta / d U partials,
-//                                                         Z = gamma Zt + beta sum_t attn -> global, transposed through LDS
+//   c0  c0[h][t] = ge_h . (bc_h + pe_t) + g_attn          all operands from LDS, under the x stream; second half of x requested
+//   H1  statistics of the forward -> xhat = gamma xn + beta, in place
+//   H3  dot[h][t] = sum_c r[h][c] xhat[t][c]              packed FMAs; reduce-scatter over the four lane quarters
+//   H4  ga = (dot + c0) * keep;  gs = a (ga - sum_t a ga) keep read off attn / attn_pre; one cross-wave exchange; attn -> aL
+//                                                         (LDS operand of the Z pass), gs -> GS (global, for the dx kernel)
+//   H5z Zt[h][c] = sum_t attn xhat                        per pixel on the MFMA, xhat staged through LDS as in the forward (F5);
+//                                                         sum_t attn per (h, px) from aL on the way
+//   H6a r again; m1 and the Z part of m2 (GroupNorm-backward means, closed forms from r, Z, asum); Z -> global, transposed
+//   H5v Vt[h][c] = sum_t gs xhat                          second MFMA pass (the accumulators of both do not fit beside x);
+//                                                         d s0 partial from aL on the way
+//   H6b d U partial of the tile, the V part of m2, d bc partial
 constexpr int RB_RP = 68;                          // rL pitch per (head, pixel): 64 c + 4
 constexpr int RB_A = 0;                            // aL [64 t][16 px][16 h] (pitch R_TP); before: exchange scratch + geL; between the passes: pU; later zT
 constexpr int RB_GE = RB_A + 4096;                 // geL [16 h][16 j][16 px] (head pitch RB_GH): the tile of g_emb, until aL is filled
