@@ -257,17 +257,20 @@ typedef struct c2s_ltae_desc {
 int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                       const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
                       const int* valid, float* attn, float* attn_pre, float* emb, float* stats, void* stream);
-/* Same operation with a caller-provided workspace (c2s_ltae_fwd_workspace_floats): when the pixel count fills the chip
- * with 64-pixel tiles (TimeUNet: L-TAE at full resolution) and C == 64 the streaming kernels are used (lane = pixel,
- * 256-byte row segments, weights through the scalar cache); otherwise, or with workspace == NULL, the 16-pixel LDS
- * kernel of c2s_ltae_attn_fwd. */
+/* Same operation with a caller-provided workspace (c2s_ltae_fwd_workspace_floats).  When the pixel count fills the chip
+ * (TimeUNet: L-TAE at full resolution) and C == 64 the full-resolution kernels are used: the register-resident kernel on
+ * 16-pixel tiles (x read once; h*w a multiple of 16, >= 4 tiles per CU) or, for other shapes, the streaming kernel on
+ * 64-pixel tiles (lane = pixel, 256-byte row segments, weights through the scalar cache); otherwise, or with
+ * workspace == NULL, the 16-pixel LDS kernel of c2s_ltae_attn_fwd.  All of them compute the same function to fp32
+ * rounding; the choice is made from the descriptor alone. */
 size_t c2s_ltae_fwd_workspace_floats(const c2s_ltae_desc* d);
 int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                          const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
                          const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
                          float* workspace, size_t ws_floats, void* stream);
-/* 1 when this shape runs the streaming kernels on the current device (forward: with a workspace and attn_pre;
- * backward: additionally needs g_emb), 0 for the 16-/8-pixel LDS kernels.  Lets tests assert which path they cover. */
+/* 1 when this shape runs the full-resolution (register-resident or streaming) kernels on the current device (forward: with
+ * a workspace and attn_pre; backward: additionally needs g_emb), 0 for the 16-/8-pixel LDS kernels.  Lets tests assert
+ * which path they cover. */
 int c2s_ltae_uses_streaming(const c2s_ltae_desc* d);
 size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
 /* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],
