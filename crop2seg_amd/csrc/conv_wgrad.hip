@@ -443,19 +443,24 @@ constexpr int WW_GP = 130;     // gout tile pitch per channel:      4 x 32 = 128
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams p) {
+// CB = input-channel blocks of 32 per workgroup.  CB = 2 (layers with a multiple of 64 input channels): one 8-wave workgroup
+// per CU instead of two 4-wave ones, waves 0-3 / 4-7 on the two blocks, ONE gradient tile in LDS for both -- every operand is
+// read once (with CB = 1 the gradient tile is fetched once per input block: 1.58 GB instead of 1.07 GB on 64 -> 64 @128x128).
+template <int CB>
+__global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd_kernel(WgradParams p) {
     constexpr int XR = 6, XC = 34;
-    constexpr int NXI = 32 * XR * 8;               // interior float4 items of the raw tile
-    constexpr int NXH = 2 * 32 * XR;               // halo scalars
+    constexpr int NTH = 256 * CB, CW = 32 * CB;    // threads, input channels of the workgroup
+    constexpr int NXI = CW * XR * 8;               // interior float4 items of the raw tile
+    constexpr int NXH = 2 * CW * XR;               // halo scalars
     constexpr int NG = 64 * 4 * 8;                 // gout float4 items
-    constexpr int XI_PT = NXI / 256, XH_PT = (NXH + 255) / 256, G_PT = NG / 256;
+    constexpr int XI_PT = NXI / NTH, XH_PT = (NXH + NTH - 1) / NTH, G_PT = NG / NTH;
     extern __shared__ float lds[];
-    float* Xl = lds;                               // [32 cin][WW_XP]
-    float* Gl = lds + 32 * WW_XP;                  // [64 cout][WW_GP]
+    float* Xl = lds;                               // [CW cin][WW_XP]
+    float* Gl = lds + CW * WW_XP;                  // [64 cout][WW_GP]
 
-    const int tid = threadIdx.x, lane = tid & 63, xi = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, xi = (tid >> 6) & 3, cbh = tid >> 8;
     const int li = lane & 31, lk = lane >> 5;
-    const int cb = blockIdx.y * 32, ob = blockIdx.z * 64;
+    const int cb0 = blockIdx.y * CW, cb = cb0 + cbh * 32, ob = blockIdx.z * 64;
     const int slice = blockIdx.x;
     const int Cin = p.C0 + p.C1;
     const int HW = p.Hin * p.Win;
@@ -486,13 +491,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
         const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
 #pragma unroll
         for (int i = 0; i < XI_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             const int j = e & 7, rr = e >> 3;
-            const int c = rr & 31, r = rr >> 5;
+            const int c = rr % CW, r = rr / CW;
             int gy = oy0 - 1 + r;
             bool ok = true;
             if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
-            const int cg = cb + c;
+            const int cg = cb0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok && cg < Cin) {
                 const float* sp = cg < p.C0 ? s0n + (size_t)cg * HW : s1n + (size_t)(cg - p.C0) * HW;
@@ -502,17 +507,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
         }
 #pragma unroll
         for (int i = 0; i < XH_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             float v = 0.f;
             if (e < NXH) {
                 const int side = e & 1, rr = e >> 1;
-                const int c = rr & 31, r = rr >> 5;
+                const int c = rr % CW, r = rr / CW;
                 int gy = oy0 - 1 + r;
                 int gx = side == 0 ? ox0 - 1 : ox0 + 32;
                 bool ok = true;
                 if (reflect) { gy = reflect_idx(gy, p.Hin); gx = reflect_idx(gx, p.Win); }
                 else ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-                const int cg = cb + c;
+                const int cg = cb0 + c;
                 if (ok && cg < Cin) {
                     const float* sp = cg < p.C0 ? s0n + (size_t)cg * HW : s1n + (size_t)(cg - p.C0) * HW;
                     v = sp[(size_t)gy * p.Win + gx];
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
         const float* gn = p.gout + (size_t)n * p.Cout * HW;
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             const int j = e & 7, rr = e >> 3;
             const int o = rr & 63, r = rr >> 6;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -534,24 +539,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < XI_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             const int j = e & 7, rr = e >> 3;
-            const int c = rr & 31, r = rr >> 5;
+            const int c = rr % CW, r = rr / CW;
             float* d = Xl + c * WW_XP + r * XC + 1 + 4 * j;
             d[0] = xi4[i].x; d[1] = xi4[i].y; d[2] = xi4[i].z; d[3] = xi4[i].w;
         }
 #pragma unroll
         for (int i = 0; i < XH_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             if (e < NXH) {
                 const int side = e & 1, rr = e >> 1;
-                const int c = rr & 31, r = rr >> 5;
+                const int c = rr % CW, r = rr / CW;
                 Xl[c * WW_XP + r * XC + (side == 0 ? 0 : XC - 1)] = xh[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             const int j = e & 7, rr = e >> 3;
             const int o = rr & 63, r = rr >> 6;
             // the pitch keeps rows 8-byte (not 16-byte) aligned: two ds_write_b64
@@ -573,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
     auto load_ops = [&](int kk, f32x2w (&d)[4], f32x2w (&g)[2][2]) {
         const int t = 2 * kk + lk;
         const int by = t >> 4, bx = t & 15;
-        const float* pa = Xl + li * WW_XP + (2 * by + ra) * XC + 2 * bx;
-        const float* pb = Xl + li * WW_XP + (2 * by + rb) * XC + 2 * bx;
+        const float* pa = Xl + (cbh * 32 + li) * WW_XP + (2 * by + ra) * XC + 2 * bx;
+        const float* pb = Xl + (cbh * 32 + li) * WW_XP + (2 * by + rb) * XC + 2 * bx;
         d[0] = *reinterpret_cast<const f32x2w*>(pa);
         d[1] = *reinterpret_cast<const f32x2w*>(pa + 2);
         d[2] = *reinterpret_cast<const f32x2w*>(pb);
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winograd_kernel(WgradParams
     // ---- dW = Gt dU G inside the workgroup (16 -> 9 values per (cin, cout): 44 % less slab traffic and no separate
     // transform launch): the nu direction is lane-local, the xi direction goes through LDS, one kx column per round.
     // Slab layout [slice][ky*3+kx][CinP][CoutB] = the generic one, summed over slices by wgrad_reduce_kernel.
-    float* ex = lds;                                   // [xi 4][m 2][r 16][lane 64]; the tiles are done (barrier above)
+    float* ex = lds + cbh * (4 * 2 * 16 * 64);         // [xi 4][m 2][r 16][lane 64] per input block; the tiles are done (barrier above)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -775,6 +780,7 @@ void init_hook() {
     C2S_RAISE_LDS((conv_wgrad_kernel<3, 1>));
     C2S_RAISE_LDS((conv_wgrad_kernel<1, 1>));
     C2S_RAISE_LDS((conv_wgrad_kernel<4, 2>));
+    C2S_RAISE_LDS(conv_wgrad_winograd_kernel<2>);
 }
 C2sInitRegistrar registrar(init_hook);
 
@@ -804,9 +810,16 @@ extern "C" int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const 
         p.tiles_y = d->Hout / 4;
         p.ntiles = d->N * p.tiles_x * p.tiles_y;
         p.log2pc = 5;
-        const size_t ldsb = ((size_t)32 * WW_XP + (size_t)64 * WW_GP) * sizeof(float);
-        dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
-        hipLaunchKernelGGL(conv_wgrad_winograd_kernel, grid, dim3(256), ldsb, st, p);
+        static const bool wide_ok = [] { const char* e = getenv("C2S_WGRAD_WINO_CB2"); return !(e && e[0] == '0'); }();
+        if (wide_ok && p.CinP % 64 == 0) {
+            const size_t ldsb = ((size_t)64 * WW_XP + (size_t)64 * WW_GP) * sizeof(float);
+            dim3 grid(p.nslices, p.CinP / 64, p.CoutB / 64);
+            hipLaunchKernelGGL(conv_wgrad_winograd_kernel<2>, grid, dim3(512), ldsb, st, p);
+        } else {
+            const size_t ldsb = ((size_t)32 * WW_XP + (size_t)64 * WW_GP) * sizeof(float);
+            dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
+            hipLaunchKernelGGL(conv_wgrad_winograd_kernel<1>, grid, dim3(256), ldsb, st, p);
+        }
         C2S_CHECK_LAUNCH("conv_wgrad_winograd");
         return C2S_OK;
     }
