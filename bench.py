@@ -204,6 +204,7 @@ def main():
         dt = float(tmax)
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
+    assert step.ws.sync_error() == 0, "a one-pass normalisation wait gave up (sync area error word set)"
 
     if rank == 0:
         ms = [a.elapsed_time(b) for a, b in prof["events"]]

@@ -83,6 +83,9 @@ SIGNATURES = {
     "c2s_norm_fwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, P, P, P, P, P, I, P, SZ, P, F, P]),
     "c2s_norm_bwd": (I, [C.POINTER(NormDesc), P, P, P, P, P, I, P, P, P, P, P, SZ, P, P]),
     "c2s_norm_bwd_params": (I, [C.POINTER(NormDesc), P, P, P, P, P, P]),
+    "c2s_norm_onepass_sync_bytes": (SZ, [C.POINTER(NormDesc), I]),
+    "c2s_norm_fwd_onepass": (I, [C.POINTER(NormDesc), P, P, P, P, P, P, P, P, P, P, I, P, F, P, SZ, P]),
+    "c2s_norm_bwd_onepass": (I, [C.POINTER(NormDesc), P, P, P, P, P, I, P, P, P, P, P, SZ, P, P, SZ, P]),
     "c2s_frame_flags": (I, [P, P, I, L, F, P]),
     "c2s_ltae_attn_fwd": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P]),
     "c2s_positional_table": (I, [P, P, L, C.c_float, P]),
@@ -110,8 +113,11 @@ SIGNATURES = {
     "c2s_confusion_add": (I, [P, P, P, L, I, P]),
     "c2s_loss_meter_add": (I, [P, P, P]),
     "c2s_boundary_target": (I, [P, P, I, I, I, P]),
+    "c2s_region_relabel": (I, [P, P, I, I, I, I, C.c_longlong, P]),
     "c2s_focal_ce_workspace_floats": (SZ, []),
     "c2s_focal_ce": (I, [P, P, P, P, I, I, I, F, C.c_longlong, I, P, SZ, P]),
+    "c2s_smooth_ce_workspace_floats": (SZ, []),
+    "c2s_smooth_ce": (I, [P, P, P, P, P, P, I, I, I, I, F, C.c_longlong, I, P, SZ, P]),
     "c2s_collate_series": (I, [P, I, P, P, P, P, P, I, I, I, I, I, C.POINTER(I), C.POINTER(F), C.POINTER(F), F, P]),
     "c2s_softmax_stitch": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "c2s_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P, F, P]),

@@ -806,6 +806,7 @@ extern "C" int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const 
     p.CoutB = cdiv(d->Cout, 64) * 64;
     hipStream_t st = (hipStream_t)stream;
     if (wino_wgrad(d)) {
+        c2s_ensure_init();      // conv_wgrad_winograd_kernel<2> needs 84 KB of dynamic LDS: the raise lives in the init hook
         p.tiles_x = d->Wout / 32;
         p.tiles_y = d->Hout / 4;
         p.ntiles = d->N * p.tiles_x * p.tiles_y;

@@ -100,6 +100,23 @@ __global__ __launch_bounds__(256) void boundary_target_kernel(const int64_t* __r
     }
 }
 
+// test_region of iterate() (utils.py:362-373): 'boundary' keeps the boundary pixels (interior -> ignore label), 'interior'
+// keeps the interior (boundary -> ignore label); boundary = get_dilated(y, K, 4).sum(1) > 1, as above.
+__global__ __launch_bounds__(256) void region_relabel_kernel(const int64_t* __restrict__ y, int64_t* __restrict__ out, int B,
+                                                             int H, int W, int keep_boundary, long long ignore_label) {
+    const long total = (long)B * H * W;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int x = (int)(e % W), r = (int)((e / W) % H);
+        const int64_t c = y[e];
+        int diff = 0;
+        if (r > 0) diff |= y[e - W] != c;
+        if (r < H - 1) diff |= y[e + W] != c;
+        if (x > 0) diff |= y[e - 1] != c;
+        if (x < W - 1) diff |= y[e + 1] != c;
+        out[e] = (diff != 0) == (keep_boundary != 0) ? c : ignore_label;
+    }
+}
+
 // FocalCELoss (size_average=True, weight=None): part[block] = (sum over kept pixels of -(1-pt)^g log pt, #kept)
 __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                         float* __restrict__ part, int B, int K, int HW, float gamma,
@@ -172,6 +189,85 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
     }
 }
 
+// SmoothCrossEntropy2D (smooth_loss.py:58-84): soft targets from the 4-neighbourhood dilation of the label map -- the classes
+// present at a pixel or its 4 neighbours (zero padding) share 1 - eps*(K - n) evenly, every other class gets eps = ls/K;
+// pixels labelled `bg_index` take the fixed distribution `bg` instead (background_treatment) -- then CrossEntropyLoss with
+// probability targets: mean over ALL B*H*W pixels of -sum_k w_k t_k log_softmax(z)_k.  One pass: the class set of a pixel is
+// a bit mask built from five labels (no one-hot tensor, no depthwise convolution), the loss term and d/dz of the pixel come
+// from the same softmax.  part[block] = (sum of pixel losses, labels outside [0,K) seen -- the reference's one_hot raises
+// on those; here they are counted and the pixel contributes nothing).
+__global__ __launch_bounds__(256) void smooth_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        const float* __restrict__ class_w, const float* __restrict__ bg,
+                                                        float* __restrict__ part, float* __restrict__ glogits, int B, int K,
+                                                        int H, int W, float ls, long long bg_index) {
+    __shared__ float red[4][2];
+    const int HW = H * W;
+    const long total = (long)B * HW;
+    const float eps = ls / (float)K;
+    const float inv_n = 1.f / (float)total;
+    float num = 0.f, bad = 0.f;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int pix = (int)(e % HW), b = (int)(e / HW);
+        const int x = pix % W, r = pix / W;
+        const float* lp = logits + (size_t)b * K * HW + pix;
+        float* gp = glogits ? glogits + (size_t)b * K * HW + pix : nullptr;
+        const long long t = target[e];
+        if (t < 0 || t >= K) {
+            bad += 1.f;
+            if (gp) for (int k = 0; k < K; ++k) gp[(size_t)k * HW] = 0.f;
+            continue;
+        }
+        unsigned mask = 1u << (int)t;
+        if (r > 0) { const long long v = target[e - W]; if (v >= 0 && v < K) mask |= 1u << (int)v; }
+        if (r < H - 1) { const long long v = target[e + W]; if (v >= 0 && v < K) mask |= 1u << (int)v; }
+        if (x > 0) { const long long v = target[e - 1]; if (v >= 0 && v < K) mask |= 1u << (int)v; }
+        if (x < W - 1) { const long long v = target[e + 1]; if (v >= 0 && v < K) mask |= 1u << (int)v; }
+        const float nd = (float)__popc(mask);
+        const float exp_small = eps * ((float)K - nd);
+        const float exp_large = (1.f - exp_small) / nd;
+        const bool is_bg = bg != nullptr && t == bg_index;
+        float mx = lp[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[(size_t)k * HW]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(lp[(size_t)k * HW] - mx);
+        const float lse = mx + logf(s);
+        const float inv_s = 1.f / s;
+        float loss = 0.f, wsum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float tk = is_bg ? bg[k] : (((mask >> k) & 1u) ? exp_large : eps);
+            const float wt = (class_w ? class_w[k] : 1.f) * tk;
+            loss -= wt * (lp[(size_t)k * HW] - lse);
+            wsum += wt;
+        }
+        num += loss;
+        if (gp) {
+            for (int k = 0; k < K; ++k) {
+                const float tk = is_bg ? bg[k] : (((mask >> k) & 1u) ? exp_large : eps);
+                const float wt = (class_w ? class_w[k] : 1.f) * tk;
+                const float pk = expf(lp[(size_t)k * HW] - mx) * inv_s;
+                gp[(size_t)k * HW] = (pk * wsum - wt) * inv_n;
+            }
+        }
+    }
+    num = wave_sum(num); bad = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[blockIdx.x * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ void smooth_ce_finalize_kernel(const float* __restrict__ part, float* __restrict__ tot, float* __restrict__ loss,
+                                          int blocks, double npix, int accumulate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double num = 0, bad = 0;
+    for (int i = 0; i < blocks; ++i) { num += part[i * 2]; bad += part[i * 2 + 1]; }
+    tot[0] = (float)num; tot[1] = (float)bad;
+    const float l = (float)(num / npix);
+    *loss = accumulate ? *loss + l : l;
+}
+
 inline int grid_for(long n, int cap = 2048) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -214,6 +310,15 @@ extern "C" int c2s_boundary_target(const long long* y, long long* y_b, int B, in
     return C2S_OK;
 }
 
+extern "C" int c2s_region_relabel(const long long* y, long long* y_out, int B, int H, int W, int keep_boundary,
+                                  long long ignore_label, void* stream) {
+    C2S_REQUIRE(y && y_out && y != y_out && B > 0 && H > 0 && W > 0, "region_relabel: bad args (out of place only)");
+    hipLaunchKernelGGL(region_relabel_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       (const int64_t*)y, (int64_t*)y_out, B, H, W, keep_boundary, ignore_label);
+    C2S_CHECK_LAUNCH("region_relabel");
+    return C2S_OK;
+}
+
 extern "C" size_t c2s_focal_ce_workspace_floats(void) { return 2 * FOCAL_BLOCKS + 2; }
 
 extern "C" int c2s_focal_ce(const float* logits, const long long* target, float* loss, float* glogits, int B, int K, int HW,
@@ -235,5 +340,26 @@ extern "C" int c2s_focal_ce(const float* logits, const long long* target, float*
                            glogits, B, K, HW, gamma, ignore_index);
         C2S_CHECK_LAUNCH("focal_bwd");
     }
+    return C2S_OK;
+}
+
+extern "C" size_t c2s_smooth_ce_workspace_floats(void) { return 2 * FOCAL_BLOCKS + 2; }
+
+extern "C" int c2s_smooth_ce(const float* logits, const long long* target, const float* class_w, const float* bg_distrib,
+                             float* loss, float* glogits, int B, int K, int H, int W, float label_smoothing,
+                             long long bg_index, int accumulate_loss, float* workspace, size_t ws_floats, void* stream) {
+    C2S_REQUIRE(logits && target && loss && workspace, "smooth_ce: null pointer");
+    C2S_REQUIRE(B > 0 && H > 0 && W > 0 && K >= 1 && K <= MAXK, "smooth_ce: 1 <= K <= 32 classes");
+    C2S_REQUIRE(label_smoothing >= 0.f && label_smoothing <= 1.f, "smooth_ce: label_smoothing outside [0, 1]");
+    C2S_REQUIRE(ws_floats >= c2s_smooth_ce_workspace_floats(), "smooth_ce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = grid_for((long)B * H * W, FOCAL_BLOCKS);
+    float* tot = workspace + 2 * FOCAL_BLOCKS;
+    hipLaunchKernelGGL(smooth_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, (const int64_t*)target, class_w, bg_distrib,
+                       workspace, glogits, B, K, H, W, label_smoothing, bg_index);
+    C2S_CHECK_LAUNCH("smooth_ce");
+    hipLaunchKernelGGL(smooth_ce_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks, (double)B * H * W,
+                       accumulate_loss);
+    C2S_CHECK_LAUNCH("smooth_ce_finalize");
     return C2S_OK;
 }

@@ -410,6 +410,365 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     if (lane == 0) part[item * 3 + 2] = sdx;
 }
 
+// ================================================================= one-pass forms
+// The two-pass forms above read every activation twice per direction (statistics / sums, then apply): 8 tensor passes per
+// layer and step, the largest HBM consumer of a train step (profiles/r02_step_traffic.csv: 12.1 of 30.4 GB).  The one-pass
+// forms read once: a wave keeps its (row, segment) in registers (32 floats per lane), publishes its partial sums, and the
+// waves of a normalisation group meet through memory before they apply from registers -- 5 passes instead of 8.
+//
+// Hand-off = data-tagged granules (MI355X_MICROARCH.md, inter-workgroup visibility: 8-byte {data, tag} words written by ONE
+// sc1 store and read by sc1 loads need no ordering, no counter and no fence): wave w of a group stores its two partial sums
+// as two granules {value, epoch} at gran[first granule of the group + w]; wave 0 of every workgroup sweeps the granules of
+// its group (lane = granule) until all carry this launch's epoch, merges them in the fixed order of the two-pass form
+// (double: bit-identical results), and hands the two group values to the other waves through LDS.  The epoch word only
+// grows (the last workgroup of a launch advances it), so granules of earlier launches -- of any shape, the area is shared
+// by all layers of a stream -- never match and nothing is ever cleared: the area only has to be all zero before its first
+// use.  The grid is persistent (at most the workgroups the chip holds at once, positions dealt round-robin), so every
+// workgroup a sweep waits for is resident; a sweep gives up after 2^17 rounds (~0.2 s), raises the error word (header
+// word 3) instead of hanging the queue, and launches on an area whose error word is set do not wait at all.
+struct SyncView {
+    unsigned* hdr;                 // [0] finished workgroups, [2] epoch, [3] error
+    unsigned long long* gran;      // [nitems][2] {float bits | epoch << 32}
+};
+__host__ __device__ inline size_t sync_bytes(long nitems) { return 64 + (size_t)nitems * 16; }
+__device__ __forceinline__ SyncView sync_view(void* base) {
+    SyncView v;
+    v.hdr = reinterpret_cast<unsigned*>(base);
+    v.gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(base) + 64);
+    return v;
+}
+constexpr int OP_MAXG = 8;         // granule pairs per lane of the sweeping wave: groups of up to 512 waves
+
+__device__ __forceinline__ void onepass_begin(const SyncView& sv, unsigned* s_hdr, unsigned& epoch, bool& poisoned) {
+    if (threadIdx.x == 0) {
+        s_hdr[0] = __hip_atomic_load(&sv.hdr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_hdr[1] = __hip_atomic_load(&sv.hdr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    epoch = s_hdr[0] + 1u;
+    poisoned = s_hdr[1] != 0u;    // an earlier sweep on this area gave up: its state is unknown, nothing waits on it any more
+}
+// the last workgroup to finish advances the epoch (every workgroup has read it by then)
+__device__ __forceinline__ void onepass_end(const SyncView& sv, unsigned epoch) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned f = __hip_atomic_fetch_add(&sv.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f + 1u == gridDim.x) {
+            __hip_atomic_store(&sv.hdr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sv.hdr[2], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ void onepass_publish(const SyncView& sv, long v, unsigned epoch, float p0, float p1, int lane) {
+    if (lane == 0) {
+        const unsigned long long e = (unsigned long long)epoch << 32;
+        __hip_atomic_store(&sv.gran[v * 2 + 0], e | __float_as_uint(p0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sv.gran[v * 2 + 1], e | __float_as_uint(p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// sweep of the wpg granule pairs of the group that starts at granule g0 (one wave): on return pa[w], pb[w] (LDS) hold the two
+// partial sums of wave w of the group.  Rolled over 64-granule rounds (two rounds of loads in flight): a sweep needs a
+// handful of registers next to the activation the wave keeps.
+__device__ __forceinline__ void onepass_sweep(const SyncView& sv, long g0, int wpg, unsigned epoch, int lane, bool poisoned,
+                                              float* __restrict__ pa, float* __restrict__ pb) {
+    for (int polls = poisoned ? (1 << 17) : 0;; ++polls) {
+        bool hit = true;
+#pragma unroll 2
+        for (int w = lane; w < wpg; w += 64) {
+            const unsigned long long ga = __hip_atomic_load(&sv.gran[(g0 + w) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long gb = __hip_atomic_load(&sv.gran[(g0 + w) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hit = hit && (unsigned)(ga >> 32) == epoch && (unsigned)(gb >> 32) == epoch;
+            pa[w] = __uint_as_float((unsigned)ga);
+            pb[w] = __uint_as_float((unsigned)gb);
+        }
+        if (__all(hit)) break;
+        if (polls > (1 << 17)) {
+            if (lane == 0) __hip_atomic_store(&sv.hdr[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave reads its own LDS writes next
+}
+
+// Position -> (group, position in the group, row, segment): the waves of a group are consecutive positions (GROUP: rows of a
+// group are consecutive anyway; BATCH: the rows (n, c) of channel c for all n).
+struct OnepassItem { int grp, w, seg; long row; };
+__device__ __forceinline__ OnepassItem onepass_item(long v, const c2s_norm_desc& d, int segs) {
+    const bool batch = d.kind == C2S_NORM_BATCH;
+    const int cpg = batch ? 1 : d.C / d.groups;
+    const int n_rows = batch ? d.N : cpg;
+    const int ipg = n_rows * segs;
+    OnepassItem it;
+    it.grp = (int)(v / ipg);
+    it.w = (int)(v - (long)it.grp * ipg);
+    const int r = it.w / segs;
+    it.seg = it.w - r * segs;
+    it.row = batch ? (long)r * d.C + it.grp : (long)it.grp * cpg + r;
+    return it;
+}
+
+// NK = float4 per lane: every segment is exactly NK*256 floats; a group is one wave or a whole number of workgroups
+// (the host checks both), so the four waves of a workgroup always work on one group.
+template <int NK, bool RES>
+__global__ __launch_bounds__(256, 4) void norm_onepass_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ rmean,
+                                                               float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                               float* __restrict__ gstats, float* __restrict__ row_ab,
+                                                               const float* __restrict__ res, float* __restrict__ y,
+                                                               const int* __restrict__ valid, c2s_norm_desc d, int segs,
+                                                               long nitems, int relu, float pad_value, void* sync) {
+    __shared__ unsigned s_hdr[2];
+    __shared__ float s_stat[2][2];
+    __shared__ float s_part[2][OP_MAXG * 64];
+    const SyncView sv = sync_view(sync);
+    unsigned epoch;
+    bool poisoned;
+    onepass_begin(sv, s_hdr, epoch, poisoned);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = d.C, HW = d.HW;
+    const bool batch = d.kind == C2S_NORM_BATCH;
+    const int cpg = batch ? 1 : C / d.groups;
+    const int wpg = (batch ? d.N : cpg) * segs;
+    constexpr int L = NK * 256;
+    const long quads = (nitems + 3) >> 2;
+    int par = 0;
+    for (long q = blockIdx.x; q < quads; q += gridDim.x, par ^= 1) {
+        const long v = q * 4 + wave;
+        const bool live = v < nitems;                              // only a single-wave-group launch has a ragged last quad
+        const OnepassItem it = onepass_item(live ? v : nitems - 1, d, segs);
+        const long row = it.row;
+        const int n = (int)(row / C), c = (int)(row % C);
+        const size_t base = (size_t)row * HW + (size_t)it.seg * L;
+        const bool ok = valid == nullptr || valid[n] != 0;       // BATCH launches come without flags (host check)
+        if (!ok) {                                               // uniform over the workgroup when it meets (wpg % 4 == 0)
+            if (live) {
+                if (it.seg == 0 && lane == 0) {
+                    row_ab[row * 3] = 0.f; row_ab[row * 3 + 1] = 0.f; row_ab[row * 3 + 2] = 0.f;
+                    if (c % cpg == 0) { gstats[it.grp * 2] = 0.f; gstats[it.grp * 2 + 1] = 0.f; }
+                }
+                f32x4 pv = {pad_value, pad_value, pad_value, pad_value};
+#pragma unroll
+                for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x4*>(y + base + lane * 4 + 256 * k) = pv;
+            }
+            continue;
+        }
+        f32x4 xv[NK], rv[RES ? NK : 1];
+        float pmean = 0.f, m2 = 0.f;
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) xv[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) s += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
+            s = wave_sum(s);
+            pmean = s / (float)L;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const float a = xv[k].x - pmean, b = xv[k].y - pmean, cc = xv[k].z - pmean, dd = xv[k].w - pmean;
+                m2 += (a * a + b * b) + (cc * cc + dd * dd);
+            }
+            m2 = wave_sum(m2);
+            if (wpg > 1) onepass_publish(sv, v, epoch, pmean, m2, lane);
+            if constexpr (RES) {                                 // in flight while the group meets
+#pragma unroll
+                for (int k = 0; k < NK; ++k) rv[k] = *reinterpret_cast<const f32x4*>(res + base + lane * 4 + 256 * k);
+            }
+        }
+        float mu, rstd, unb;
+        bool leader;                                             // the wave that leaves the group's statistics behind
+        if (wpg > 1) {
+            if (wave == 0) {
+                onepass_sweep(sv, v - it.w, wpg, epoch, lane, poisoned, s_part[0], s_part[1]);
+                // group_mean_rstd of the two-pass form on the swept partials (same order, same arithmetic)
+                double cnt = 0.0, sum = 0.0;
+                for (int w = lane; w < wpg; w += 64) { cnt += L; sum += (double)s_part[0][w] * L; }
+                for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sum += __shfl_xor(sum, o, 64); }
+                const double mean = cnt > 0 ? sum / cnt : 0.0;
+                double mm = 0.0;
+                for (int w = lane; w < wpg; w += 64) { const double dm = (double)s_part[0][w] - mean; mm += (double)s_part[1][w] + dm * dm * L; }
+                for (int o = 32; o > 0; o >>= 1) mm += __shfl_xor(mm, o, 64);
+                const double var = cnt > 0 ? mm / cnt : 0.0;
+                mu = (float)mean;
+                rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+                unb = (float)(cnt > 1 ? mm / (cnt - 1.0) : var);
+                if (lane == 0) { s_stat[par][0] = mu; s_stat[par][1] = rstd; }
+            }
+            __syncthreads();
+            if (wave != 0) { mu = s_stat[par][0]; rstd = s_stat[par][1]; unb = 0.f; }
+            leader = it.w == 0;                                  // wave 0 of the group's first workgroup
+        } else {
+            const double var = (double)m2 / L;
+            mu = pmean;
+            rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+            unb = (float)(L > 1 ? (double)m2 / (L - 1.0) : var);
+            leader = live;
+        }
+        if (!live) continue;
+        if (leader && lane == 0) {
+            gstats[it.grp * 2] = mu; gstats[it.grp * 2 + 1] = rstd;
+            if (batch && rmean != nullptr) {
+                rmean[it.grp] = (1.f - d.momentum) * rmean[it.grp] + d.momentum * mu;
+                rvar[it.grp] = (1.f - d.momentum) * rvar[it.grp] + d.momentum * unb;
+            }
+            if (batch && it.grp == 0 && nbt != nullptr) *nbt += 1;
+        }
+        const float a = gamma[c] * rstd, b = beta[c];
+        if (it.seg == 0 && lane == 0) { row_ab[row * 3] = a; row_ab[row * 3 + 1] = b; row_ab[row * 3 + 2] = mu; }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (xv[k][e] - mu) * a + b;
+                if (relu) t = fmaxf(t, 0.f);
+                if constexpr (RES) t += rv[k][e];
+                o[e] = t;
+            }
+            *reinterpret_cast<f32x4*>(y + base + lane * 4 + 256 * k) = o;
+        }
+    }
+    onepass_end(sv, epoch);
+}
+
+template <int NK>
+__global__ __launch_bounds__(256, 4) void norm_onepass_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ row_ab,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ gstats, float* __restrict__ gx,
+                                                               float* __restrict__ part, const int* __restrict__ valid,
+                                                               c2s_norm_desc d, int segs, long nitems, int relu,
+                                                               void* sync) {
+    __shared__ unsigned s_hdr[2];
+    __shared__ float s_stat[2][2];
+    __shared__ float s_part[2][OP_MAXG * 64];
+    const SyncView sv = sync_view(sync);
+    unsigned epoch;
+    bool poisoned;
+    onepass_begin(sv, s_hdr, epoch, poisoned);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = d.C, HW = d.HW;
+    const bool batch = d.kind == C2S_NORM_BATCH;
+    const int cpg = batch ? 1 : C / d.groups;
+    const int n_rows = batch ? d.N : cpg;
+    const int wpg = n_rows * segs;
+    constexpr int L = NK * 256;
+    const long quads = (nitems + 3) >> 2;
+    int par = 0;
+    for (long q = blockIdx.x; q < quads; q += gridDim.x, par ^= 1) {
+        const long v = q * 4 + wave;
+        const bool live = v < nitems;
+        const OnepassItem it = onepass_item(live ? v : nitems - 1, d, segs);
+        const long row = it.row;
+        const int nn = (int)(row / C), cc = (int)(row % C);
+        const size_t base = (size_t)row * HW + (size_t)it.seg * L;
+        const long item = row * segs + it.seg;
+        if (valid != nullptr && valid[nn] == 0) {                // uniform over the workgroup when it meets
+            if (live) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x4*>(gx + base + lane * 4 + 256 * k) = z;
+                if (lane == 0) { part[item * 3] = 0.f; part[item * 3 + 1] = 0.f; part[item * 3 + 2] = 0.f; }
+            }
+            continue;
+        }
+        f32x4 xa[NK], ga[NK];
+        const float mean = gstats[it.grp * 2], rstd = gstats[it.grp * 2 + 1];
+        const float a = row_ab[row * 3], b = row_ab[row * 3 + 1], mu = row_ab[row * 3 + 2];
+        float s1 = 0.f, s2 = 0.f;
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                xa[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
+                ga[k] = *reinterpret_cast<const f32x4*>(g + base + lane * 4 + 256 * k);
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xx = xa[k][e];
+                    const float gg = (!relu || (xx - mean) * a + b > 0.f) ? ga[k][e] : 0.f;
+                    ga[k][e] = gg;                                  // masked gradient, reused by the apply step
+                    s1 += gg;
+                    s2 += gg * ((xx - mean) * rstd);
+                }
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            if (wpg > 1) onepass_publish(sv, v, epoch, s1, s2, lane);
+            if (lane == 0) { part[item * 3] = s1; part[item * 3 + 1] = s2; }     // for norm_bwd_params_kernel (a later launch)
+        }
+        float k2, k3;
+        if (wpg > 1) {
+            if (wave == 0) {
+                onepass_sweep(sv, v - it.w, wpg, epoch, lane, poisoned, s_part[0], s_part[1]);
+                // the per-row sums over the segments run in the order of row_sums(): lanes over rows
+                double A = 0.0, Bv = 0.0, cnt = 0.0;
+                for (int r = lane; r < n_rows; r += 64) {
+                    const long rr = batch ? (long)r * C + it.grp : (long)it.grp * cpg + r;
+                    const float gm = gamma[rr % C];
+                    double t1 = 0.0, t2 = 0.0;
+                    for (int sg = 0; sg < segs; ++sg) { t1 += s_part[0][r * segs + sg]; t2 += s_part[1][r * segs + sg]; }
+                    A += (double)gm * (double)(float)t1;
+                    Bv += (double)gm * (double)(float)t2;
+                    cnt += HW;
+                }
+                for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o, 64); Bv += __shfl_xor(Bv, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+                const double m = cnt > 0 ? cnt : 1.0;
+                k2 = (float)(-(double)rstd * rstd * Bv / m);
+                k3 = (float)(-(double)rstd * A / m);
+                if (lane == 0) { s_stat[par][0] = k2; s_stat[par][1] = k3; }
+            }
+            __syncthreads();
+            if (wave != 0) { k2 = s_stat[par][0]; k3 = s_stat[par][1]; }
+        } else {
+            const double gm = (double)gamma[cc];
+            k2 = (float)(-(double)rstd * rstd * (gm * (double)s2) / (double)HW);
+            k3 = (float)(-(double)rstd * (gm * (double)s1) / (double)HW);
+        }
+        if (!live) continue;
+        const float k1 = rstd * gamma[cc];
+        float sdx = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = k1 * ga[k][e] + k2 * (xa[k][e] - mu) + k3;
+                sdx += o[e];
+            }
+            *reinterpret_cast<f32x4*>(gx + base + lane * 4 + 256 * k) = o;
+        }
+        sdx = wave_sum(sdx);
+        if (lane == 0) part[item * 3 + 2] = sdx;
+    }
+    onepass_end(sv, epoch);
+}
+
+// shapes the one-pass forms take: every segment full and a power-of-two number of float4 per lane; a group is one wave or a
+// whole number of workgroups, at most 512 waves; BatchNorm only with batch statistics and without frame flags (its groups
+// span all frames)
+__host__ inline int onepass_nk(const c2s_norm_desc* d, const int* valid) {
+    const int L = seg_len(d->HW);
+    if (d->HW % L != 0 || L % 256 != 0) return 0;
+    const int nk = L / 256;
+    if (nk != 1 && nk != 2 && nk != 4 && nk != 8) return 0;
+    const bool batch = d->kind == C2S_NORM_BATCH;
+    if (batch && (!d->training || valid != nullptr)) return 0;
+    const long wpg = (long)(batch ? d->N : d->C / d->groups) * n_segs(d->HW);
+    if (wpg > 64 * OP_MAXG || (wpg != 1 && wpg % 4 != 0)) return 0;
+    return nk;
+}
+__host__ inline long norm_items(const c2s_norm_desc* d) { return (long)d->N * d->C * n_segs(d->HW); }
+
+// persistent grid: at most the workgroups the chip holds at once (every workgroup a sweep waits for must be resident)
+template <typename K>
+int onepass_grid(K kernel, long quads) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const long cap = (long)c2s_cus() * per_cu;
+    return (int)(quads < cap ? quads : cap);
+}
+
 int check_desc(const c2s_norm_desc* d) {
     C2S_REQUIRE(d && d->N > 0 && d->C > 0 && d->HW > 0, "norm: bad shape");
     C2S_REQUIRE(d->kind == C2S_NORM_GROUP || d->kind == C2S_NORM_BATCH, "norm: bad kind");
@@ -485,5 +844,73 @@ extern "C" int c2s_norm_bwd_params(const c2s_norm_desc* d, const float* workspac
     hipLaunchKernelGGL(norm_bwd_params_kernel, dim3(d->C), dim3(64), 0, (hipStream_t)stream, workspace, dgamma, dbeta, dbias,
                        valid, d->N, d->C, n_segs(d->HW));
     C2S_CHECK_LAUNCH("norm_bwd_params");
+    return C2S_OK;
+}
+
+// ---------------------------------------------------------------- one-pass entry points
+extern "C" size_t c2s_norm_onepass_sync_bytes(const c2s_norm_desc* d, int has_valid) {
+    if (!d || check_desc(d) != C2S_OK) return 0;
+    static const int dummy = 0;
+    if (onepass_nk(d, has_valid ? &dummy : nullptr) == 0) return 0;
+    return sync_bytes(norm_items(d));
+}
+
+extern "C" int c2s_norm_fwd_onepass(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    float* group_stats, float* row_ab, const float* residual, float* y, int relu,
+                                    const int* valid, float pad_value, void* sync, size_t sync_nbytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    C2S_REQUIRE(x && gamma && beta && group_stats && row_ab && y && sync, "norm_fwd_onepass: null pointer");
+    const int nk = onepass_nk(d, valid);
+    C2S_REQUIRE(nk != 0, "norm_fwd_onepass: shape not taken by the one-pass form (c2s_norm_onepass_sync_bytes() == 0): use c2s_norm_fwd");
+    const int segs = n_segs(d->HW);
+    const long nitems = norm_items(d);
+    C2S_REQUIRE(sync_nbytes >= sync_bytes(nitems), "norm_fwd_onepass: sync area too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long quads = (nitems + 3) / 4;
+#define C2S_OP_FWD(NK_, R_)                                                                                              \
+    if (nk == NK_ && (residual != nullptr) == R_) {                                                                    \
+        static thread_local int grid_cap = 0;                                                                          \
+        if (grid_cap == 0) grid_cap = onepass_grid((norm_onepass_fwd_kernel<NK_, R_>), 1L << 40);                      \
+        hipLaunchKernelGGL((norm_onepass_fwd_kernel<NK_, R_>), dim3(quads < grid_cap ? quads : grid_cap), dim3(256), 0, st, x, \
+                           gamma, beta, running_mean, running_var, num_batches_tracked, group_stats, row_ab, residual, y, \
+                           valid, *d, segs, nitems, relu, pad_value, sync);                                             \
+    }
+    C2S_OP_FWD(8, false) C2S_OP_FWD(4, false) C2S_OP_FWD(2, false) C2S_OP_FWD(1, false)
+    C2S_OP_FWD(8, true) C2S_OP_FWD(4, true) C2S_OP_FWD(2, true) C2S_OP_FWD(1, true)
+#undef C2S_OP_FWD
+    C2S_CHECK_LAUNCH("norm_onepass_fwd");
+    return C2S_OK;
+}
+
+extern "C" int c2s_norm_bwd_onepass(const c2s_norm_desc* d, const float* x, const float* g, const float* gamma,
+                                    const float* group_stats, const float* row_ab, int relu, float* gx, float* dgamma,
+                                    float* dbeta, float* dbias, float* workspace, size_t ws_floats, const int* valid,
+                                    void* sync, size_t sync_nbytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    C2S_REQUIRE(x && g && gamma && group_stats && row_ab && gx && workspace && sync, "norm_bwd_onepass: null pointer");
+    C2S_REQUIRE(ws_floats >= c2s_norm_workspace_floats(d), "norm_bwd_onepass: workspace too small");
+    const int nk = onepass_nk(d, valid);
+    C2S_REQUIRE(nk != 0, "norm_bwd_onepass: shape not taken by the one-pass form (c2s_norm_onepass_sync_bytes() == 0): use c2s_norm_bwd");
+    const int segs = n_segs(d->HW);
+    const long nitems = norm_items(d);
+    C2S_REQUIRE(sync_nbytes >= sync_bytes(nitems), "norm_bwd_onepass: sync area too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long quads = (nitems + 3) / 4;
+#define C2S_OP_BWD(NK_)                                                                                                 \
+    if (nk == NK_) {                                                                                                    \
+        static thread_local int grid_cap = 0;                                                                           \
+        if (grid_cap == 0) grid_cap = onepass_grid(norm_onepass_bwd_kernel<NK_>, 1L << 40);                             \
+        hipLaunchKernelGGL(norm_onepass_bwd_kernel<NK_>, dim3(quads < grid_cap ? quads : grid_cap), dim3(256), 0, st, x, \
+                           g, row_ab, gamma, group_stats, gx, workspace, valid, *d, segs, nitems, relu, sync);           \
+    }
+    C2S_OP_BWD(8) C2S_OP_BWD(4) C2S_OP_BWD(2) C2S_OP_BWD(1)
+#undef C2S_OP_BWD
+    C2S_CHECK_LAUNCH("norm_onepass_bwd");
+    if (dgamma != nullptr || dbeta != nullptr || dbias != nullptr) {
+        hipLaunchKernelGGL(norm_bwd_params_kernel, dim3(d->C), dim3(64), 0, st, workspace, dgamma, dbeta, dbias, valid, d->N,
+                           d->C, segs);
+        C2S_CHECK_LAUNCH("norm_bwd_params");
+    }
     return C2S_OK;
 }

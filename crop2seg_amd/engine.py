@@ -32,6 +32,14 @@ _SIDE = None
 SIDE_WGRAD = _os.environ.get("C2S_WGRAD_STREAM", "1") != "0"
 SIDE_BATCH = int(_os.environ.get("C2S_WGRAD_BATCH", "8"))
 SIDE_FLUSH_POSITIONS = int(_os.environ.get("C2S_WGRAD_FLUSH_POSITIONS", str(1 << 19)))
+# While a hipGraph is being captured the fork / join events become cross-stream edges of the graph: the replayed step keeps
+# the two-stream overlap of the eager step.  C2S_GRAPH_SIDE=0 captures everything on one stream (round-2 behaviour).
+GRAPH_SIDE = _os.environ.get("C2S_GRAPH_SIDE", "1") != "0"
+
+
+def _side_ok() -> bool:
+    """Parameter-gradient launches go to the side stream (eager always; under capture when GRAPH_SIDE)."""
+    return SIDE_WGRAD and (GRAPH_SIDE or not torch.cuda.is_current_stream_capturing())
 
 
 def _side_stream():
@@ -78,6 +86,20 @@ class Workspace:
             outs[key] = (out, src_ptr)
         self.pack_plan = {"table": table.to(self.device), "njobs": len(jobs), "blocks": block, "outs": outs}
         self.pack_record = {}
+
+    def sync_area(self, nbytes: int) -> Tensor:
+        """Zero-initialised area for kernels whose workgroups meet through memory (one-pass normalisation): all zero at rest
+        (the kernels restore that state themselves), one area per workspace = per stream of launches."""
+        b = self.bufs.get("sync")
+        if b is None or b.numel() < nbytes:
+            b = torch.zeros(max(int(nbytes), 4096), device=self.device, dtype=torch.uint8)
+            self.bufs["sync"] = b
+        return b
+
+    def sync_error(self) -> int:
+        """Error word of the sync area (host synchronisation: diagnostics / tests only): non-zero when a wait gave up."""
+        b = self.bufs.get("sync")
+        return 0 if b is None else int(b[:16].view(torch.int32)[3])
 
     def get(self, name: str, nfloats: int) -> Tensor:
         b = self.bufs.get(name)
@@ -357,7 +379,7 @@ def _wgrad(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int,
            pad_mode: int, dst: Tensor, so: int, sc: int, taps: Sequence[int], accumulate: int,
            valid: Optional[Tensor]) -> None:
     """Weight gradient of a convolution into `dst` (split-K slabs + fixed-order slice sum), on the side stream."""
-    if SIDE_WGRAD and ctx.tape is not None and not torch.cuda.is_current_stream_capturing():   # a captured graph gained nothing from the fork
+    if ctx.tape is not None and _side_ok():
         ctx.tape.defer(lambda: _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps,
                                              accumulate, valid), [gout, *srcs])
         if srcs[0].shape[0] * Hout * Wout >= SIDE_FLUSH_POSITIONS:
@@ -535,7 +557,7 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
             if acc:
                 check(lib().c2s_add_inplace(gw.data_ptr(), tgt.data_ptr(), tgt.numel(), _stream()), "add_inplace")
 
-        if SIDE_WGRAD and not torch.cuda.is_current_stream_capturing():
+        if _side_ok():
             tape.defer(wgrad, [x, g, tgt])              # side stream, next to the data-gradient chain
         else:
             wgrad()
@@ -553,6 +575,15 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
 # =================================================================================================
 # normalisation (+ReLU, +residual)
 # =================================================================================================
+# One-pass normalisation (csrc/norm.hip): statistics / sums and the apply step in ONE read of the activation, the waves of a
+# group meeting through memory.  C2S_NORM_ONEPASS=0 keeps the two-pass kernels (A/B runs, and the shapes the one-pass
+# form does not take fall back to them anyway).
+ONEPASS_NORM = _os.environ.get("C2S_NORM_ONEPASS", "1") != "0"
+# Below full 2048-float segments a wave holds too little data for the meeting to pay (tools/norm_bench.py: 32x32 planes break
+# even, 16x16 planes lose 30-140 %): those layers keep the two-pass kernels.
+ONEPASS_MIN_HW = int(_os.environ.get("C2S_NORM_ONEPASS_MIN_HW", "2048"))
+
+
 def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: bool, residual: Optional[Tensor],
              valid: Optional[Tensor], pad_value: float = 0.0, conv_bias: Optional[str] = None, affine: bool = True) -> Tensor:
     """GroupNorm / BatchNorm (+ReLU) (+ residual add) on NCHW x.  `conv_bias` names the bias of the convolution
@@ -579,9 +610,18 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
     ws = ctx.ws.get("norm", nws)
     y = torch.empty_like(x)
     nbt = ctx.b.get(prefix + ".num_batches_tracked") if (batch and ctx.training) else None   # int64, bumped by the kernel
-    check(lib().c2s_norm_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv), _ptr(nbt),
-                             gstats.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(), int(relu),
-                             ws.data_ptr(), ws.numel(), _ptr(valid), float(pad_value), _stream()), "norm_fwd")
+    sync_bytes = (lib().c2s_norm_onepass_sync_bytes(C.byref(d), 1 if valid is not None else 0)
+                  if ONEPASS_NORM and HW >= ONEPASS_MIN_HW else 0)
+    if sync_bytes:
+        sync = ctx.ws.sync_area(sync_bytes)
+        check(lib().c2s_norm_fwd_onepass(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
+                                         _ptr(nbt), gstats.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(),
+                                         int(relu), _ptr(valid), float(pad_value), sync.data_ptr(), sync.numel(), _stream()),
+              "norm_fwd_onepass")
+    else:
+        check(lib().c2s_norm_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv), _ptr(nbt),
+                                 gstats.data_ptr(), row_ab.data_ptr(), _ptr(residual), y.data_ptr(), int(relu),
+                                 ws.data_ptr(), ws.numel(), _ptr(valid), float(pad_value), _stream()), "norm_fwd")
     if ctx.tape is None:
         return y
     tape = ctx.tape
@@ -603,20 +643,29 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
             dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
             dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
         dbias = ctx.grad_sink(conv_bias)[0] if conv_bias else None
-        if SIDE_WGRAD and not torch.cuda.is_current_stream_capturing():
+
+        def norm_bwd(ws_, dg_, db_, dbi_):
+            if sync_bytes:
+                sync = ctx.ws.sync_area(sync_bytes)
+                check(lib().c2s_norm_bwd_onepass(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
+                                                 row_ab.data_ptr(), int(relu), gx.data_ptr(), _ptr(dg_), _ptr(db_), _ptr(dbi_),
+                                                 ws_.data_ptr(), ws_.numel(), _ptr(valid), sync.data_ptr(), sync.numel(),
+                                                 _stream()), "norm_bwd_onepass")
+            else:
+                check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
+                                         row_ab.data_ptr(), int(relu), gx.data_ptr(), _ptr(dg_), _ptr(db_), _ptr(dbi_),
+                                         ws_.data_ptr(), ws_.numel(), _ptr(valid), _stream()), "norm_bwd")
+
+        if _side_ok():
             # the parameter gradients (one wave per channel: a launch that leaves the GPU idle) go to the side stream; their
             # partial sums live in a buffer of their own until the join
             ws2 = torch.empty(nws, device=x.device, dtype=torch.float32)
-            check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
-                                     row_ab.data_ptr(), int(relu), gx.data_ptr(), None, None, None, ws2.data_ptr(),
-                                     ws2.numel(), _ptr(valid), _stream()), "norm_bwd")
+            norm_bwd(ws2, None, None, None)
             tape.defer(lambda: check(lib().c2s_norm_bwd_params(C.byref(d), ws2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                               _ptr(dbias), _ptr(valid), _stream()), "norm_bwd_params"), [ws2])
+                                                               _ptr(dbias), _ptr(valid), _stream()), "norm_bwd_params"),
+                       [ws2] if affine else [ws2, dgamma, dbeta])     # affine=False: the discarded sums are temporaries too
         else:
-            ws2 = ctx.ws.get("norm", nws)
-            check(lib().c2s_norm_bwd(C.byref(d), x.data_ptr(), g.data_ptr(), gamma.data_ptr(), gstats.data_ptr(),
-                                     row_ab.data_ptr(), int(relu), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                     _ptr(dbias), ws2.data_ptr(), ws2.numel(), _ptr(valid), _stream()), "norm_bwd")
+            norm_bwd(ctx.ws.get("norm", nws), dgamma, dbeta, dbias)
         tape.add_grad(x, gx)
 
     tape.record(bwd)

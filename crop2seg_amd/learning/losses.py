@@ -1,7 +1,7 @@
 """Boundary-loss pieces of the reference's training loop as HIP kernels.
 
 Reference: src/learning/utils.py:198-222 (get_dilated), :283-285 (y_b), :318-324 (loss = CE + focal on the boundary
-head), src/learning/focal_loss.py:7-44 (FocalCELoss).  No autograd graph: `focal_ce` returns the loss and, on request,
+head), src/learning/focal_loss.py:7-44 (FocalCELoss), src/learning/smooth_loss.py:18-84 (SmoothCrossEntropy2D).  No autograd graph: `focal_ce` returns the loss and, on request,
 dL/dlogits -- the train step feeds that into the engine's tape.
 """
 from __future__ import annotations
@@ -60,3 +60,82 @@ class FocalCELoss:
 
     def __call__(self, preds: Tensor, target: Tensor) -> Tensor:
         return focal_ce(preds, target, self.gamma, self.ignore_index)[0][0]
+
+
+DEFAULT_CLASS_PROPORTIONS = (0.3111, 0.0193, 0.0809, 0.2809, 0.1084, 0.0892, 0.0350, 0.0170, 0.0007,
+                             0.0047, 0.0015, 0.0044, 0.0394, 0.0074)          # smooth_loss.py:28-29 (S2TSCZCrop)
+
+
+def smooth_ce(logits: Tensor, target: Tensor, label_smoothing: float = 0.1, class_w: Optional[Tensor] = None,
+              bg_distrib: Optional[Tensor] = None, bg_index: int = 0, want_grad: bool = False,
+              ws: Optional[E.Workspace] = None, loss_out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Tensor]:
+    """One pass of c2s_smooth_ce: returns (loss[1], dlogits | None, counters[2]) -- counters[1] is the number of labels
+    outside [0, K) the pass met (a device value: reading it synchronises)."""
+    if not logits.is_cuda:
+        raise RuntimeError("crop2seg_amd runs on MI355X only (no CPU fallback)")
+    logits = logits.contiguous()
+    target = target.to(torch.int64).contiguous()
+    B, K, H, W = logits.shape
+    ws = ws or E.Workspace(logits.device)
+    w = ws.get("smooth_ce", lib().c2s_smooth_ce_workspace_floats())
+    loss = loss_out if loss_out is not None else torch.empty(1, device=logits.device, dtype=torch.float32)
+    gl = torch.empty_like(logits) if want_grad else None
+    check(lib().c2s_smooth_ce(logits.data_ptr(), target.data_ptr(), E._ptr(class_w), E._ptr(bg_distrib), loss.data_ptr(),
+                              E._ptr(gl), B, K, H, W, float(label_smoothing), int(bg_index), 1 if loss_out is not None else 0,
+                              w.data_ptr(), w.numel(), E._stream()), "smooth_ce")
+    return loss, gl, w[w.numel() - 2:]
+
+
+class SmoothCrossEntropy2D:
+    """Call-compatible with the reference's criterion (smooth_loss.py:18-84; constructor arguments in the same order):
+    label smoothing that follows the field borders -- classes present in the 4-neighbourhood of a pixel share the target
+    mass -- with the fixed distribution for background pixels, then CE with probability targets (reduction 'mean').
+    The value carries no autograd graph; `grad()` returns dL/dlogits of the last call with want_grad=True (TrainStep feeds
+    it into the tape).  `check_targets()` raises if the last call met labels outside [0, K) -- the reference's one_hot
+    raises there; the kernel skips and counts them instead of faulting."""
+
+    def __init__(self, weight: Optional[Tensor] = None, size_average=None, ignore_index: int = -100, reduce=None,
+                 reduction: str = "mean", label_smoothing: float = 0.1, background_treatment: bool = True,
+                 background_index: int = 0, background_label_value: float = 0.6,
+                 class_proportions=DEFAULT_CLASS_PROPORTIONS):
+        if reduction != "mean" or size_average is not None or reduce is not None:
+            raise NotImplementedError("SmoothCrossEntropy2D: only reduction='mean' is built")
+        self.weight, self.ls = weight, float(label_smoothing)
+        self.background_treatment, self.background_index = bool(background_treatment), int(background_index)
+        bd = torch.tensor([background_label_value] + list(class_proportions), dtype=torch.float32)
+        bd[1:] *= 1 - background_label_value                     # smooth_loss.py:78-80
+        self._bg_host = bd
+        self._bg_dev: Optional[Tensor] = None
+        self._w_dev: Optional[Tensor] = None
+        self._ws: Optional[E.Workspace] = None
+        self._last = None
+
+    def __call__(self, input: Tensor, target: Tensor, want_grad: bool = False) -> Tensor:
+        assert input.dim() == 4, f"`input` is expected to have 4 dimensions (B x N_CLASSES x H x W) but is of shape {input.shape}"
+        assert target.dim() == 3, f"`target` is expected to have 3 dimensions (B x H x W) but is of shape {target.shape}"
+        bg = None
+        if self.background_treatment:
+            if self._bg_host.numel() != input.shape[1]:
+                raise ValueError(f"background distribution has {self._bg_host.numel()} entries, the logits {input.shape[1]} classes")
+            if self._bg_dev is None or self._bg_dev.device != input.device:
+                self._bg_dev = self._bg_host.to(input.device)
+            bg = self._bg_dev
+        cw = None
+        if self.weight is not None:
+            if self._w_dev is None or self._w_dev.device != input.device:
+                self._w_dev = self.weight.detach().to(input.device, torch.float32).contiguous()
+            cw = self._w_dev
+        if self._ws is None or self._ws.device != input.device:
+            self._ws = E.Workspace(input.device)
+        loss, gl, counters = smooth_ce(input, target, self.ls, cw, bg, self.background_index, want_grad, self._ws)
+        self._last = (gl, counters)
+        return loss[0]
+
+    forward = __call__
+
+    def grad(self) -> Optional[Tensor]:
+        return None if self._last is None else self._last[0]
+
+    def check_targets(self) -> None:
+        if self._last is not None and float(self._last[1][1]) != 0.0:
+            raise ValueError(f"SmoothCrossEntropy2D: {int(float(self._last[1][1]))} target labels outside [0, n_classes)")

@@ -144,16 +144,48 @@ class StepMeters:
     ties resolve to the lower class index here, so the second class is the reference's wherever the three largest logits
     of a pixel are distinct."""
 
-    def __init__(self, num_classes: int, ignore_index=None, device="cuda"):
+    def __init__(self, num_classes: int, ignore_index=None, device="cuda", add_boundary_loss: bool = False,
+                 test_region: str = "all"):
+        """add_boundary_loss: a third meter for the 2-class boundary head (utils.py:258-259,383-384).
+        test_region: 'all' | 'boundary' | 'interior' (utils.py:362-373): the other region's pixels are relabelled to the
+        ignore label [0..K)[ignore_index] before the meters see them (needs an int ignore_index, as in the reference)."""
+        assert test_region in ("all", "boundary", "interior"), test_region
         self.iou = IoU(num_classes, ignore_index=ignore_index, cm_device=device)
         self.iou_top2 = IoU(num_classes, ignore_index=ignore_index, cm_device=device)
+        self.iou_boundary = IoU(2, cm_device=device) if add_boundary_loss else None      # IoU(num_classes=2), utils.py:259
         self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
         self.num_classes = num_classes
+        self.test_region = test_region
+        if test_region != "all":
+            if not isinstance(ignore_index, int):
+                raise ValueError("test_region needs an int ignore_index (the reference indexes range(num_classes) with it)")
+            self.ignore_label = list(range(num_classes))[ignore_index]
 
     def reset(self) -> None:
         self.iou.reset()
         self.iou_top2.reset()
+        if self.iou_boundary is not None:
+            self.iou_boundary.reset()
         self.loss_acc.zero_()
+
+    def region_target(self, y: Tensor) -> Tensor:
+        """y as the meters see it under `test_region` (utils.py:362-373)."""
+        if self.test_region == "all":
+            return y
+        y = y.to(torch.int64).contiguous()
+        B, H, W = y.shape
+        out = torch.empty_like(y)
+        check(lib().c2s_region_relabel(y.data_ptr(), out.data_ptr(), B, H, W, 1 if self.test_region == "boundary" else 0,
+                                       int(self.ignore_label), _stream()), "region_relabel")
+        return out
+
+    def update_boundary(self, out_b: Tensor, y_b: Tensor) -> None:
+        """iou_meter_boundary.add(out_b.argmax(1), y_b) (utils.py:342,383-384); the arg-max runs inside the kernel."""
+        assert self.iou_boundary is not None, "StepMeters(add_boundary_loss=True)"
+        self.iou_boundary.add(out_b, y_b)
+
+    def get_miou_acc_boundary(self) -> Tuple[float, float]:
+        return self.iou_boundary.get_miou_acc()
 
     def update(self, out: Tensor, y: Tensor, loss: Optional[Tensor] = None, want_pred: bool = False):
         """out [B,K,H,W] f32 logits, y [B,H,W] int64, loss: 1-element device tensor.  Returns (pred, pred_top2) int64
@@ -162,7 +194,7 @@ class StepMeters:
         B, K = out.shape[:2]
         assert K == self.num_classes and out.dtype == torch.float32
         out = out.contiguous()
-        y = y.to(torch.int64).contiguous()
+        y = self.region_target(y.to(torch.int64).contiguous())
         HW = out[0, 0].numel()
         pred = torch.empty_like(y) if want_pred else None
         pred2 = torch.empty_like(y) if want_pred else None

@@ -35,21 +35,24 @@ class SeriesCollator:
     `max_size` pads to a fixed T (pad_collate's max_size), else to the longest series of the batch."""
 
     def __init__(self, channels_order: Optional[Sequence[int]] = None, mean=None, std=None, pad_value: float = 0.0,
-                 device="cuda", max_size: Optional[int] = None, mode: str = "zero_copy"):
+                 device="cuda", max_size: Optional[int] = None, mode: str = "zero_copy", slots: int = 2):
         assert mode in ("zero_copy", "staged")
         self.order = list(channels_order) if channels_order is not None else None
         self.mean = None if mean is None else np.ascontiguousarray(np.asarray(mean, dtype=np.float32))
         self.std = None if std is None else np.ascontiguousarray(np.asarray(std, dtype=np.float32))
         assert (self.mean is None) == (self.std is None), "mean and std come together"
         self.pad_value, self.device, self.max_size, self.mode = float(pad_value), torch.device(device), max_size, mode
-        self._pinned: Optional[Tensor] = None        # raw series, back to back
-        self._meta: Optional[Tensor] = None          # offsets [B+1] | dates [sum T_b]   (int64, pinned)
-        self._dev_raw: Optional[Tensor] = None
+        # `slots` staging sets (pinned raw buffer, pinned offsets/dates table, device copies, an event): the kernel (zero_copy)
+        # or the H2D copies (staged) read pinned memory asynchronously, so a set is only rewritten after the event recorded
+        # behind its last launch has completed -- with two sets the host can stage batch N+1 while the GPU consumes batch N
+        self._slots = [dict(pinned=None, meta=None, dev_raw=None, meta_dev=None, event=None) for _ in range(max(1, int(slots)))]
+        self._next = 0
 
-    def _pin(self, nbytes: int) -> Tensor:
-        if self._pinned is None or self._pinned.numel() < nbytes:
-            self._pinned = torch.empty(max(nbytes, 1), dtype=torch.uint8).pin_memory()
-        return self._pinned
+    @staticmethod
+    def _pin(slot: dict, nbytes: int) -> Tensor:
+        if slot["pinned"] is None or slot["pinned"].numel() < nbytes:
+            slot["pinned"] = torch.empty(max(nbytes, 1), dtype=torch.uint8).pin_memory()
+        return slot["pinned"]
 
     def __call__(self, series: Sequence[np.ndarray], dates: Sequence[np.ndarray]) -> Tuple[Tensor, Tensor, Tensor]:
         if self.device.type != "cuda":
@@ -69,29 +72,33 @@ class SeriesCollator:
         Cc = len(order)
         frame = Cs * H * W
         total = sum(lengths)
-        # stage: one pinned buffer, series back to back (a loader can np.load straight into `staging_view` instead)
-        pin = self._pin(total * frame * dt.itemsize)
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % len(self._slots)
+        if slot["event"] is not None:
+            slot["event"].synchronize()           # the launch that last read this set's pinned memory has finished
+        # stage: one pinned buffer, series back to back
+        pin = self._pin(slot, total * frame * dt.itemsize)
         host = pin.numpy()[: total * frame * dt.itemsize].view(dt).reshape(total, Cs, H, W)
         off = 0
         for s in series:
             host[off:off + s.shape[0]] = s
             off += s.shape[0]
-        if self._meta is None or self._meta.numel() < B + 1 + total:
-            self._meta = torch.empty(B + 1 + total, dtype=torch.int64).pin_memory()
-        meta = self._meta.numpy()
+        if slot["meta"] is None or slot["meta"].numel() < B + 1 + total:
+            slot["meta"] = torch.empty(B + 1 + total, dtype=torch.int64).pin_memory()
+        meta = slot["meta"].numpy()
         meta[0] = 0
         meta[1:B + 1] = np.cumsum(lengths)
         meta[B + 1:B + 1 + total] = np.concatenate([np.asarray(d, dtype=np.int64) for d in dates])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.mode == "staged":
             nby = total * frame * dt.itemsize
-            if self._dev_raw is None or self._dev_raw.numel() < nby:
-                self._dev_raw = torch.empty(nby, dtype=torch.uint8, device=self.device)
-            self._dev_raw[:nby].copy_(pin[:nby], non_blocking=True)
-            src_ptr = self._dev_raw.data_ptr()
+            if slot["dev_raw"] is None or slot["dev_raw"].numel() < nby:
+                slot["dev_raw"] = torch.empty(nby, dtype=torch.uint8, device=self.device)
+            slot["dev_raw"][:nby].copy_(pin[:nby], non_blocking=True)
+            src_ptr = slot["dev_raw"].data_ptr()
         else:
             src_ptr = pin.data_ptr()
-        meta_dev = self._meta[:B + 1 + total].to(self.device, non_blocking=True)
+        meta_dev = slot["meta"][:B + 1 + total].to(self.device, non_blocking=True)
         x = torch.empty(B, T, Cc, H, W, device=self.device, dtype=torch.float32)
         dd = torch.empty(B, T, device=self.device, dtype=torch.int64)
         valid = torch.empty(B * T, device=self.device, dtype=torch.int32)
@@ -103,8 +110,67 @@ class SeriesCollator:
         check(lib().c2s_collate_series(src_ptr, _SRC[dt], meta_dev.data_ptr(), meta_dev.data_ptr() + 8 * (B + 1), x.data_ptr(),
                                        dd.data_ptr(), valid.data_ptr(), B, T, Cc, Cs, H * W, order_a, mean_a, std_a,
                                        self.pad_value, stream), "collate_series")
-        self._last = (meta_dev,)      # keep the device copy alive until the stream has consumed it
+        slot["meta_dev"] = meta_dev    # the device copy stays alive until this set is reused (after its event)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot["event"] = ev
         return x, dd, valid
+
+
+class PrefetchLoader:
+    """Runs a SeriesCollator one batch ahead of the training stream.
+
+    `batches` yields (series list, dates list, target array | None).  A worker thread copies batch N+1 into the collator's
+    free pinned set (numpy copies release the GIL) and launches its collate kernel on a copy stream while the caller's
+    stream is busy with batch N; the consumer side only waits on the event recorded behind that launch.  The reference
+    loads with `num_workers=0` on the training thread (train.py:331-346), so its step waits for every host copy."""
+
+    def __init__(self, batches, collator: SeriesCollator, depth: int = 1):
+        import queue
+        import threading
+        self.coll = collator
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        dev = collator.device
+        self._dev = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self._stream = torch.cuda.Stream(device=self._dev)
+        self._err: Optional[BaseException] = None
+        self._thread = threading.Thread(target=self._work, args=(iter(batches),), daemon=True)
+        self._thread.start()
+
+    def _work(self, it) -> None:
+        try:
+            torch.cuda.set_device(self._dev)
+            for series, dates, target in it:
+                with torch.cuda.stream(self._stream):
+                    x, dd, valid = self.coll(series, dates)
+                    y = None
+                    if target is not None:
+                        y = torch.as_tensor(np.asarray(target)).pin_memory().to(self.coll.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                self._q.put((x, dd, valid, y, ev))
+        except BaseException as e:      # surfaced on the consumer side
+            self._err = e
+        finally:
+            self._q.put(None)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is None:
+            self._thread.join()
+            if self._err is not None:
+                raise self._err
+            raise StopIteration
+        x, dd, valid, y, ev = item
+        cur = torch.cuda.current_stream(self.coll.device)
+        cur.wait_event(ev)
+        for t in (x, dd, valid, y):
+            if t is not None:
+                t.record_stream(cur)      # allocated on the copy stream, consumed on the caller's
+        return x, dd, valid, y
 
 
 def pad_collate(batch, pad_value=0, max_size=None, device="cuda", channels_order=None, mean=None, std=None):

@@ -227,6 +227,28 @@ int c2s_norm_bwd(const c2s_norm_desc* d, const float* x, const float* g, const f
 int c2s_norm_bwd_params(const c2s_norm_desc* d, const float* workspace, float* dgamma, float* dbeta, float* dbias,
                         const int* valid, void* stream);
 
+/* One-pass forms of the two calls above (same results and reference call sites; same arithmetic in the same order): the
+ * activation is read ONCE per direction.  A wave keeps its (row, 2048-float segment) in registers, publishes its partial
+ * sums as tagged 8-byte words in `sync`, and one wave per workgroup sweeps the words of its normalisation group before
+ * the workgroup applies from registers (5 tensor passes per layer and step instead of 8).  `sync` is caller-provided
+ * device memory of c2s_norm_onepass_sync_bytes() bytes, ALL ZERO before its first use and never cleared afterwards
+ * (tags carry a launch epoch kept in the area); one area serves every launch of ONE stream, of any shape (launches that
+ * may run concurrently need areas of their own).  The grid is persistent and sized to what the device holds at once.
+ * Word 3 of the area is an error flag: non-zero if a sweep gave up (it never hangs).
+ * c2s_norm_onepass_sync_bytes returns 0 for shapes the one-pass form does not take (HW not a whole number of full
+ * segments of 256 / 512 / 1024 / 2048 floats; groups of more than 512 segments or, above one segment, not a multiple
+ * of 4 segments; BatchNorm in eval mode or with frame flags): use c2s_norm_fwd / c2s_norm_bwd there.  has_valid: whether
+ * the call will pass frame flags. */
+size_t c2s_norm_onepass_sync_bytes(const c2s_norm_desc* d, int has_valid);
+int c2s_norm_fwd_onepass(const c2s_norm_desc* d, const float* x, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked, float* group_stats,
+                         float* row_ab, const float* residual, float* y, int relu, const int* valid, float pad_value,
+                         void* sync, size_t sync_bytes, void* stream);
+int c2s_norm_bwd_onepass(const c2s_norm_desc* d, const float* x, const float* g, const float* gamma,
+                         const float* group_stats, const float* row_ab, int relu, float* gx, float* dgamma, float* dbeta,
+                         float* dbias, float* workspace, size_t ws_floats, const int* valid, void* sync,
+                         size_t sync_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Frame flags: valid[n] = any(x[n] != pad_value)   (utae.py:201-203, temp_shared_block.py:31)
  * ------------------------------------------------------------------------------------------------ */
@@ -374,10 +396,24 @@ int c2s_metrics_update(const float* logits, const long long* target, long long* 
 int c2s_confusion_add(const long long* pred, const long long* target, long long* conf, long n, int K, void* stream);
 int c2s_loss_meter_add(const float* loss, double* acc, void* stream);
 int c2s_boundary_target(const long long* y, long long* y_b, int B, int H, int W, void* stream);
+/* test_region of iterate() (utils.py:362-373): keep_boundary != 0: 'boundary' (interior pixels -> ignore_label), else
+ * 'interior' (boundary pixels -> ignore_label); boundary as in c2s_boundary_target.  Out of place (y_out != y). */
+int c2s_region_relabel(const long long* y, long long* y_out, int B, int H, int W, int keep_boundary, long long ignore_label,
+                       void* stream);
 size_t c2s_focal_ce_workspace_floats(void);
 int c2s_focal_ce(const float* logits, const long long* target, float* loss, float* glogits, int B, int K, int HW,
                  float gamma, long long ignore_index, int accumulate_loss, float* workspace, size_t ws_floats,
                  void* stream);
+/* SmoothCrossEntropy2D (smooth_loss.py:18-84): soft targets from the 4-neighbourhood dilation of the label map (classes
+ * present at the pixel or a 4-neighbour share 1 - eps*(K - n) evenly, the others get eps = label_smoothing / K; pixels
+ * labelled bg_index take bg_distrib[K] instead when it is non-NULL: background_treatment), then CrossEntropyLoss with
+ * probability targets and optional class weights: loss = mean over all B*H*W pixels of -sum_k w_k t_k log_softmax(z)_k.
+ * glogits (may be NULL) receives dL/dlogits.  workspace[2*512 + 1] holds the number of labels outside [0, K) the pass
+ * met (the reference raises on them; here such a pixel contributes nothing and is counted). */
+size_t c2s_smooth_ce_workspace_floats(void);
+int c2s_smooth_ce(const float* logits, const long long* target, const float* class_w, const float* bg_distrib, float* loss,
+                  float* glogits, int B, int K, int H, int W, float label_smoothing, long long bg_index, int accumulate_loss,
+                  float* workspace, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch movers on either side of the path.

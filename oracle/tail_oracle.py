@@ -114,6 +114,36 @@ def smooth_targets(target: torch.Tensor, n_classes: int, label_smoothing: float 
     return torch.where(dilated.permute(1, 0, 2, 3) == 1, exp_large, eps).permute(1, 0, 2, 3)
 
 
+def region_target(y: torch.Tensor, n_classes: int, test_region: str, ignore_index: int) -> torch.Tensor:
+    """test_region relabelling of iterate() (learning/utils.py:362-373)."""
+    if test_region == "all":
+        return y
+    dilated = get_dilated(y, n_classes, 4)
+    ignore_label = [i for i in range(n_classes)][ignore_index]
+    if test_region == "boundary":
+        return torch.where(dilated.sum(1) == 1, ignore_label, y)
+    return torch.where(dilated.sum(1) > 1, ignore_label, y)
+
+
+DEFAULT_CLASS_PROPORTIONS = (0.3111, 0.0193, 0.0809, 0.2809, 0.1084, 0.0892, 0.0350, 0.0170, 0.0007,
+                             0.0047, 0.0015, 0.0044, 0.0394, 0.0074)          # smooth_loss.py:28-29
+
+
+def smooth_cross_entropy_2d(logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor] = None,
+                            label_smoothing: float = 0.1, background_treatment: bool = True, background_index: int = 0,
+                            background_label_value: float = 0.6, class_proportions=DEFAULT_CLASS_PROPORTIONS) -> torch.Tensor:
+    """SmoothCrossEntropy2D.forward (smooth_loss.py:58-84): dilation soft targets, the background distribution, then
+    torch's own CrossEntropyLoss (the reference's superclass) with probability targets.  Parity unpinned: the module
+    imports src.learning.utils -> torchnet, which this image lacks; the CE itself is torch's."""
+    K = logits.shape[1]
+    target_out = smooth_targets(target, K, label_smoothing)
+    if background_treatment:
+        bd = torch.tensor([background_label_value] + list(class_proportions), dtype=torch.float32)
+        bd[1:] *= 1 - background_label_value
+        target_out = torch.where(target[:, None, ...] == background_index, bd[:, None, None], target_out)
+    return torch.nn.CrossEntropyLoss(weight=weight)(logits, target_out)
+
+
 # ------------------------------------------------------------------------------------------------ N1: collate
 CHANNELS_LIKE_PASTIS = [2, 1, 0, 4, 5, 6, 3, 7, 8, 9]          # s2_ts_cz_crop.py:248, train.py:291
 

@@ -173,3 +173,138 @@ def test_predict_tile_equals_patch_by_patch():
     assert bool((top1.cpu() == rt)[(top2[0] - top2[1]) > 1e-6].all())
     p1, t1 = predict_tile(net, x, dates, grid=grid, crop=90, batch_size=1)
     assert torch.equal(p1, proba) and torch.equal(t1, top1), "batched inference must equal the B=1 loop bit for bit"
+
+
+@pytest.mark.parametrize("mode", ["zero_copy", "staged"])
+@pytest.mark.parametrize("slots", [1, 2])
+def test_collator_back_to_back_calls_do_not_overwrite_each_other(mode, slots):
+    """The collate kernel / H2D copies read pinned memory asynchronously: a second call must not rewrite the staging set
+    of the first before the GPU has consumed it (the stream is kept busy so that the host runs ahead)."""
+    from crop2seg_amd.utils import CHANNELS_LIKE_PASTIS, SeriesCollator
+    rng = np.random.default_rng(5)
+    lengths = [9, 12, 7, 11]
+    batches = []
+    for k in range(3):
+        series = [rng.integers(0, 12000, (t, 10, 64, 64)).astype(np.int16) for t in lengths]
+        dates = [np.sort(rng.integers(1, 400, t)).astype(np.int64) for t in lengths]
+        batches.append((series, dates))
+    mean, std = rng.normal(1200, 300, 10), rng.uniform(300, 900, 10)
+    coll = SeriesCollator(CHANNELS_LIKE_PASTIS, mean, std, mode=mode, slots=slots)
+    busy = torch.randn(4096, 4096, device="cuda")
+    for _ in range(40):                       # ~ tens of ms of queued GPU work in front of the first collate launch
+        busy = busy @ busy * 1e-3
+    outs = [coll(s, d) for s, d in batches]   # no synchronisation in between
+    torch.cuda.synchronize()
+    for (s, d), (x, dd, _) in zip(batches, outs):
+        rx, rd = TO.collate_series(s, d, CHANNELS_LIKE_PASTIS, mean, std)
+        assert torch.equal(x.cpu(), rx) and torch.equal(dd.cpu(), rd)
+
+
+def test_prefetch_loader_yields_the_same_batches():
+    from crop2seg_amd.utils import CHANNELS_LIKE_PASTIS, PrefetchLoader, SeriesCollator
+    rng = np.random.default_rng(9)
+    batches = []
+    for k in range(5):
+        lengths = [int(t) for t in rng.integers(3, 9, 3)]
+        series = [rng.integers(0, 12000, (t, 10, 32, 32)).astype(np.uint16) for t in lengths]
+        dates = [np.sort(rng.integers(1, 400, t)).astype(np.int64) for t in lengths]
+        batches.append((series, dates, rng.integers(0, 15, (3, 32, 32)).astype(np.int64)))
+    mean, std = rng.normal(1200, 300, 10), rng.uniform(300, 900, 10)
+    loader = PrefetchLoader(batches, SeriesCollator(CHANNELS_LIKE_PASTIS, mean, std))
+    n = 0
+    for (s, d, t), (x, dd, valid, y) in zip(batches, loader):
+        rx, rd = TO.collate_series(s, d, CHANNELS_LIKE_PASTIS, mean, std)
+        assert torch.equal(x.cpu(), rx) and torch.equal(dd.cpu(), rd) and np.array_equal(y.cpu().numpy(), t)
+        n += 1
+    assert n == 5
+    with pytest.raises(StopIteration):
+        next(loader)
+
+
+def test_predict_tile_timeunet_equals_patch_by_patch():
+    """N3 on the model the web app runs (prediction.py:194-202 forces model='timeunet', B=1, T ~ 60): a 2x2 tile of
+    128x128 patches with T=60 -- at B=1 the full-resolution L-TAE has exactly 4 register tiles per CU, the dispatch
+    threshold; batched inference must equal the B=1 loop bit for bit and the restatement of the loop to 1e-6."""
+    import crop2seg_amd as C2S
+    from crop2seg_amd.inference import predict_tile
+    from oracle import seeded
+    net = C2S.TimeUNet_v1(input_dim=10, out_conv=[32, 15])
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(seeded.make_state(ks, 5, "tame"))
+    net = net.cuda().eval()
+    grid, h1, T = 2, 128, 60
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(grid * grid, T, 10, h1, h1, generator=g)
+    lengths = [60, 41, 27, 55]
+    for b, tb in enumerate(lengths):
+        x[b, tb:] = 0
+    dates = (5 * torch.arange(T))[None].repeat(grid * grid, 1)
+    for b, tb in enumerate(lengths):
+        dates[b, tb:] = 0
+    x, dates = x.cuda(), dates.cuda()
+    proba, top1 = predict_tile(net, x, dates, grid=grid, crop=250, batch_size=4)
+    p1, t1 = predict_tile(net, x, dates, grid=grid, crop=250, batch_size=1)
+    assert torch.equal(p1, proba) and torch.equal(t1, top1), "batched inference must equal the B=1 loop bit for bit"
+    with torch.no_grad():
+        singles = [net(x[i:i + 1].contiguous(), batch_positions=dates[i:i + 1].contiguous()).cpu() for i in range(grid * grid)]
+    rp, rt = TO.softmax_stitch(singles, grid=grid, crop=250)
+    assert proba.shape == (15, 250, 250) and float((proba.cpu() - rp).abs().max()) <= 1e-6
+    top2 = rp.topk(2, dim=0).values
+    assert bool((top1.cpu() == rt)[(top2[0] - top2[1]) > 1e-6].all())
+
+
+@pytest.mark.parametrize("bg,weighted", [(True, False), (False, True), (True, True)])
+def test_smooth_cross_entropy_2d(bg, weighted):
+    """N4: SmoothCrossEntropy2D (smooth_loss.py:18-84) -- loss and dL/dlogits against the restatement (dilation soft targets +
+    torch's own CrossEntropyLoss with probability targets) differentiated by autograd.  Parity unpinned: the reference
+    module cannot be imported here (torchnet)."""
+    from crop2seg_amd.learning.losses import SmoothCrossEntropy2D
+    g = torch.Generator().manual_seed(31)
+    B, K, H, W = 3, 15, 40, 36
+    y = torch.randint(0, K, (B, (H + 3) // 4, (W + 3) // 4), generator=g)
+    y = y.repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W].contiguous()       # fields with borders
+    logits = (2 * torch.randn(B, K, H, W, generator=g)).requires_grad_(True)
+    cw = None
+    if weighted:
+        cw = torch.rand(K, generator=g) + 0.5
+        cw[-1] = 0
+    ref = TO.smooth_cross_entropy_2d(logits, y, cw, 0.1, background_treatment=bg)
+    ref.backward()
+    crit = SmoothCrossEntropy2D(weight=cw, label_smoothing=0.1, background_treatment=bg)
+    loss = crit(logits.detach().cuda(), y.cuda(), want_grad=True)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    gl = crit.grad().cpu()
+    assert float((gl - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
+    crit.check_targets()
+    ybad = y.clone()
+    ybad[0, 0, 0] = K
+    crit(logits.detach().cuda(), ybad.cuda())
+    with pytest.raises(ValueError, match="outside"):
+        crit.check_targets()
+
+
+@pytest.mark.parametrize("region", ["boundary", "interior"])
+def test_step_meters_test_region_and_boundary_meter(region):
+    """iterate()'s test_region relabelling (utils.py:362-373) and the boundary-head meter (utils.py:342,383-384): confusion
+    matrices bit-exact against the restatement fed through the reference-pinned confusion-matrix restatement."""
+    from crop2seg_amd.learning.losses import boundary_target
+    from crop2seg_amd.learning.metrics import StepMeters
+    g = torch.Generator().manual_seed(41)
+    B, K, H, W = 3, 15, 48, 40
+    y = torch.randint(0, K, (B, H // 4, W // 4), generator=g).repeat_interleave(4, 1).repeat_interleave(4, 2).contiguous()
+    out = torch.randn(B, K, H, W, generator=g)
+    out_b = torch.randn(B, 2, H, W, generator=g)
+    m = StepMeters(K, ignore_index=-1, add_boundary_loss=True, test_region=region)
+    yd = y.cuda()
+    y_b = boundary_target(yd)
+    for _ in range(2):
+        m.update(out.cuda(), yd, torch.tensor([0.5], device="cuda"))
+        m.update_boundary(out_b.cuda(), y_b)
+    yr = TO.region_target(y, K, region, -1)
+    assert torch.equal(m.region_target(yd).cpu(), yr)
+    rp, rp2, rc, rc2 = TO.metrics_tail(out, yr, K)
+    assert np.array_equal(m.iou.conf_metric.conf.cpu().numpy(), 2 * rc)
+    assert np.array_equal(m.iou_top2.conf_metric.conf.cpu().numpy(), 2 * rc2)
+    cb = TO.confusion_matrix(out_b.argmax(1).numpy(), TO.boundary_target(y, K).numpy(), 2)
+    assert np.array_equal(m.iou_boundary.conf_metric.conf.cpu().numpy(), 2 * cb)
+    assert m.get_miou_acc() == TO.miou_acc(2 * rc, -1) and m.get_miou_acc_boundary() == TO.miou_acc(2 * cb, None)

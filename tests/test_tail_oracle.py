@@ -84,3 +84,31 @@ def test_softmax_stitch_restatement_tiling():
     p3 = torch.softmax(patches[3], 1)[0]                 # patch (h=1, w=1) -> rows 4.., cols 4..
     assert torch.equal(proba[:, 4:7, 4:7], p3[:, :3, :3])
     assert torch.equal(t1[0:4, 4:7], torch.softmax(patches[1], 1)[0].argmax(0)[:, :3])
+
+
+def test_smooth_cross_entropy_restatement_against_a_naive_loop():
+    """SmoothCrossEntropy2D restatement (smooth_loss.py:58-84) against a per-pixel loop over the definition."""
+    import math
+    g = torch.Generator().manual_seed(2)
+    B, K, H, W = 2, 15, 6, 7
+    y = torch.randint(0, 4, (B, H, W), generator=g)
+    logits = torch.randn(B, K, H, W, generator=g)
+    got = float(TO.smooth_cross_entropy_2d(logits, y, None, 0.1, background_treatment=True))
+    bd = [0.6] + [0.4 * p for p in TO.DEFAULT_CLASS_PROPORTIONS]
+    eps, tot = 0.1 / K, 0.0
+    for b in range(B):
+        for r in range(H):
+            for c in range(W):
+                present = {int(y[b, r, c])}
+                for dr, dc in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < H and 0 <= cc < W:
+                        present.add(int(y[b, rr, cc]))
+                large = (1 - eps * (K - len(present))) / len(present)
+                t = [large if k in present else eps for k in range(K)]
+                if int(y[b, r, c]) == 0:
+                    t = bd
+                z = logits[b, :, r, c].double()
+                lse = float(torch.logsumexp(z, 0))
+                tot += -sum(t[k] * (float(z[k]) - lse) for k in range(K))
+    assert math.isclose(got, tot / (B * H * W), rel_tol=1e-5)
