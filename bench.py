@@ -56,6 +56,16 @@ def dominant_traffic(kernel_key, N, H):
     return None, None
 
 
+def ltae_kernel_name(B, T, H):
+    """The forward kernel c2s_ltae_attn_fwd_ws launches at the TimeUNet shape (C = 64, full resolution), asked of the library."""
+    import ctypes as C
+    from crop2seg_amd import _lib
+    d = _lib.LtaeDesc(B, T, 64, H * H, 16, 256, 1e-5, 0.1, 0, None, None)
+    path = _lib.lib().c2s_ltae_fwd_path(C.byref(d))
+    return {0: "ltae_fwd_kernel (16-pixel LDS kernel)", 1: "ltae_prep_kernel + ltae_stream_fwd_kernel (three-pass streaming forward)",
+            2: "ltae_reg_fwd_kernel (register-resident forward: x read once)"}.get(path, f"unknown path {path}")
+
+
 def _cpu_steps(O, sd, cfg, B, T, H, W, n_warm, n_timed):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, T, 10, H, W, generator=g)
@@ -243,7 +253,7 @@ def main():
             lbytes = 4.0 * (Ppix * T * 64 + Ppix * 256 + 2 * 16 * Ppix * T)     # x read; emb, attn, attn_pre written
             ltae_roofline = {"bound": "hbm", "achieved": lbytes / (lavg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": lbytes / (lavg * 1e-3) / 8e12, "traffic": None,
-                             "kernel": "ltae_stream_fwd (prep + streaming forward, one call)", "avg_launch_ms": lavg,
+                             "kernel": ltae_kernel_name(B, T, H), "avg_launch_ms": lavg,
                              "launches_timed": len(lms), "algorithmic_bytes_per_launch": lbytes}
         a_, b_ = STEP_FLOPS[args.model]
         step_flops = (a_ * (n_real / B) + b_) * H * H * 3.0           # per-frame terms scale with the real frames of a patch

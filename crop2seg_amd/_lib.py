@@ -92,9 +92,14 @@ SIGNATURES = {
     "c2s_ltae_fold_fwd": (I, [P] * 9 + [I, I, P]),
     "c2s_ltae_fold_bwd": (I, [P] * 16 + [I, I, I, P, SZ, P]),
     "c2s_ltae_fold_bwd_workspace_floats": (SZ, []),
+    "c2s_ltae_pe_table": (I, [I, P, P, F, P, P, P, P, P, I, P]),
+    "c2s_ltae_pe_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "c2s_ltae_pe_gattn": (I, [P, P, P, P, I, I, I, P]),
+    "c2s_ltae_pe_bwd": (I, [I] + [P] * 15 + [I, I, I, P]),
     "c2s_ltae_fwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_fwd_ws": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P, SZ, P]),
     "c2s_ltae_uses_streaming": (I, [C.POINTER(LtaeDesc)]),
+    "c2s_ltae_fwd_path": (I, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_bwd": (I, [C.POINTER(LtaeDesc)] + [P] * 22 + [SZ, P]),
     "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P, P]),

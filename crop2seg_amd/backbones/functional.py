@@ -41,6 +41,8 @@ class BackboneSpec:
     encoder: bool = False             # return (last decoder map, maps) instead of logits (utae.py:233-234)
     return_maps: bool = False         # also return the decoder feature maps (utae.py:224-231)
     pe_period: float = 1000.0
+    pe_mode: str = "rel"              # "doy" / "abs_rel" / "linear": the learnable positional encoders (tae.py:404-430)
+    num_queries: int = 1              # > 1: accepted by the constructors, the forward raises as the reference's does
     attn_dropout: float = 0.1       # reference tae.py:816
     mlp_dropout: float = 0.2        # reference tae.py:361
 
@@ -123,7 +125,8 @@ def up_conv_block(ctx, x, skip, prefix, spec):
 def ltae(ctx, x5, dates, valid, prefix, spec: BackboneSpec, drop: DropoutState, with_tail: bool):
     """LTAE.forward / LTAE4WTAE.forward (reference tae.py:451-504, 589-635)."""
     emb, attn = E.ltae_attention(ctx, x5, dates, valid, prefix, spec.n_head, spec.d_k, spec.d_model, spec.pe_period,
-                                 spec.attn_dropout, with_tail, drop.attn_seed, drop.attn_keep, drop.seed_dev)
+                                 spec.attn_dropout, with_tail, drop.attn_seed, drop.attn_keep, drop.seed_dev,
+                                 pe_mode=spec.pe_mode)
     if not with_tail:
         return None, attn
     o = E.conv2d(ctx, [emb], prefix + ".mlp.0.weight", prefix + ".mlp.0.bias", 1, 1, 0, _lib.PAD_ZEROS, None)

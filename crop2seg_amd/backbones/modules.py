@@ -126,14 +126,46 @@ class LightweightMultiHeadAttention(_Holder):
 
 
 class PositionalEncoder(_Holder):
-    """reference positional_encoding.py:7-43 (no parameters unless add_linear; the table is computed by
-    crop2seg_amd.engine.positional_table)."""
+    """reference positional_encoding.py:7-43: no parameters unless add_linear, which puts a Linear(d*repeat, d*repeat) on
+    the tiled sinusoid (the tables are computed by crop2seg_amd.engine.positional_table / c2s_ltae_pe_table)."""
 
     def __init__(self, d_model, T=1000, repeat=None, offset=0, add_linear=False):
         super().__init__()
-        if add_linear or offset != 0:
-            raise NotImplementedError("PositionalEncoder(add_linear/offset) is not built")
-        self.d, self.T, self.repeat = d_model, T, repeat
+        if offset != 0:
+            raise NotImplementedError("PositionalEncoder(offset) is not built")
+        self.d, self.T, self.repeat, self.add_linear = d_model, T, repeat, add_linear
+        if add_linear:
+            n = d_model * repeat if repeat is not None else d_model
+            self.fc = nn.Linear(n, n)
+
+
+class AbsolutePositionalEncoder(_Holder):
+    """reference positional_encoding.py:46-73: one_hot(day of year, 365) -> Linear(365, d_model), tiled `repeat` times."""
+
+    def __init__(self, d_model: int, repeat=None):
+        super().__init__()
+        self.d, self.repeat = d_model, repeat
+        self.fc = nn.Linear(365, d_model)
+
+
+def _pe_mode(use_abs_rel_enc, use_doy, add_linear) -> str:
+    """Which positional term LTAE.forward adds for a flag combination (tae.py:404-430,467-479)."""
+    if use_abs_rel_enc:
+        if use_doy or add_linear:
+            raise NotImplementedError("use_abs_rel_enc together with use_doy / add_linear is not built")
+        return "abs_rel"
+    if add_linear:
+        return "linear"                 # with or without use_doy: PositionalEncoder(add_linear=True) (tae.py:405-409,414-417)
+    return "doy" if use_doy else "rel"
+
+
+def _positional_encoders(mod, d_model, n_head, T, mode):
+    if mode == "doy":
+        mod.positional_encoder = AbsolutePositionalEncoder(d_model // n_head, repeat=n_head)
+    else:
+        mod.positional_encoder = PositionalEncoder(d_model // n_head, T=T, repeat=n_head, add_linear=mode == "linear")
+    if mode == "abs_rel":
+        mod.positional_encoder_abs = AbsolutePositionalEncoder(d_model // n_head, repeat=n_head)
 
 
 class LTAE(_Holder):
@@ -143,14 +175,16 @@ class LTAE(_Holder):
                  positional_encoding=True, use_abs_rel_enc=False, use_doy=False, num_queries=1, add_linear=False,
                  *args, **kwargs):
         super().__init__()
-        if use_abs_rel_enc or use_doy or add_linear or num_queries != 1 or not positional_encoding or d_model is None:
-            raise NotImplementedError("crop2seg_amd builds the default L-TAE (relative sinusoidal dates, one query)")
+        if not positional_encoding or d_model is None:
+            raise NotImplementedError("crop2seg_amd builds the L-TAE with an input projection and a positional encoder")
         self.in_channels, self.n_head, self.d_k, self.d_model, self.T = in_channels, n_head, d_k, d_model, T
+        self.num_queries, self.use_abs_rel_enc, self.add_linear = num_queries, use_abs_rel_enc, add_linear
+        self.pe_mode = _pe_mode(use_abs_rel_enc, use_doy, add_linear)
         self.dropout_p = dropout
         mlp = copy.deepcopy(mlp)
         assert mlp[0] == d_model and len(mlp) == 2
         self.inconv = nn.Conv1d(in_channels, d_model, 1)
-        self.positional_encoder = PositionalEncoder(d_model // n_head, T=T, repeat=n_head)
+        _positional_encoders(self, d_model, n_head, T, self.pe_mode)
         self.attention_head = LightweightMultiHeadAttention(n_head=n_head, d_k=d_k, d_in=d_model, n=num_queries)
         self.in_norm = nn.GroupNorm(num_groups=n_head, num_channels=in_channels)
         self.out_norm = nn.GroupNorm(num_groups=n_head, num_channels=mlp[-1])
@@ -165,11 +199,13 @@ class LTAE4WTAE(_Holder):
     def __init__(self, in_channels=128, n_head=16, d_k=4, d_model=256, positional_encoding=True, use_abs_rel_enc=False,
                  num_queries=1, use_doy=False, add_linear=False, *args, **kwargs):
         super().__init__()
-        if use_abs_rel_enc or use_doy or add_linear or num_queries != 1 or not positional_encoding or d_model is None:
-            raise NotImplementedError("crop2seg_amd builds the default L-TAE (relative sinusoidal dates, one query)")
+        if not positional_encoding or d_model is None:
+            raise NotImplementedError("crop2seg_amd builds the L-TAE with an input projection and a positional encoder")
         self.in_channels, self.n_head, self.d_k, self.d_model = in_channels, n_head, d_k, d_model
+        self.num_queries, self.use_abs_rel_enc, self.add_linear = num_queries, use_abs_rel_enc, add_linear
+        self.pe_mode = _pe_mode(use_abs_rel_enc, use_doy, add_linear)
         self.inconv = nn.Conv1d(in_channels, d_model, 1)
-        self.positional_encoder = PositionalEncoder(d_model // n_head, repeat=n_head)
+        _positional_encoders(self, d_model, n_head, 1000, self.pe_mode)
         self.attention_head = LightweightMultiHeadAttention(n_head=n_head, d_k=d_k, d_in=d_model, n=num_queries)
         self.in_norm = nn.GroupNorm(num_groups=n_head, num_channels=in_channels)
 
@@ -250,8 +286,18 @@ class _Backbone(nn.Module):
         H, W = input.shape[-2:]
         if H % 8 or W % 8 or H < 16 or W < 16:
             raise ValueError("H and W must be multiples of 8 and >= 16")
-        if batch_positions.dim() != 2:
-            raise NotImplementedError("batch_positions [B,T,2] (use_abs_rel_enc) is not built")
+        want = 3 if self.spec.pe_mode == "abs_rel" else 2
+        if batch_positions.dim() != want or (want == 3 and batch_positions.shape[-1] != 2):
+            raise ValueError("batch_positions must be [B,T,2] (relative date, day of year) with use_abs_rel_enc, else [B,T]")
+        if self.spec.num_queries != 1:
+            # The reference's own forward fails for num_queries > 1 (probed with the imported reference): U-TAE / W-TAE unpack a
+            # 6-D attention tensor into five names in the temporal aggregator (temporal_aggregator.py:25), TimeUNet feeds a
+            # 5-D embedding to ConvTranspose2d.  Same exception types here.
+            if self.spec.model == "timeunet":
+                raise RuntimeError("Expected 3D (unbatched) or 4D (batched) input to conv_transpose2d: num_queries > 1 yields "
+                                   "a 5-D embedding (the reference's forward raises the same way)")
+            raise ValueError("too many values to unpack (expected 5): num_queries > 1 yields a 6-D attention tensor "
+                             "(the reference's forward raises the same way, temporal_aggregator.py:25)")
 
     def forward(self, input: Tensor, batch_positions: Optional[Tensor] = None, return_att: bool = False,
                 dropout_state: Optional[Fn.DropoutState] = None, *args, **kwargs):
@@ -293,15 +339,14 @@ class _Backbone(nn.Module):
 def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k, str_conv_s, str_conv_p,
                  agg_mode, encoder_norm, n_head, d_model, d_k, encoder, return_maps, pad_value, padding_mode, conv_type,
                  use_mbconv, add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss):
-    unsupported = dict(use_mbconv=use_mbconv, add_squeeze_excit=add_squeeze_excit, use_abs_rel_enc=use_abs_rel_enc,
-                       use_doy=use_doy, add_linear=add_linear)
+    unsupported = dict(use_mbconv=use_mbconv, add_squeeze_excit=add_squeeze_excit)
     bad = [k for k, v in unsupported.items() if v]
-    if bad or num_queries != 1 or conv_type not in ("2d", "depthwise_separable") or agg_mode not in ("att_group", "att_mean", "mean"):
+    if bad or conv_type not in ("2d", "depthwise_separable") or agg_mode not in ("att_group", "att_mean", "mean"):
         raise NotImplementedError(
             "crop2seg_amd builds the reference's default blocks (train.py:32-47,153-166) plus agg_mode in {att_group, att_mean, "
-            "mean}, conv_type in {2d, depthwise_separable}, encoder_norm in {group, batch, instance}, add_boundary_loss, encoder and "
-            "return_maps; not built: "
-            f"{bad or dict(num_queries=num_queries, conv_type=conv_type, agg_mode=agg_mode)}")
+            "mean}, conv_type in {2d, depthwise_separable}, encoder_norm in {group, batch, instance}, add_boundary_loss, encoder, "
+            "return_maps and the positional encoders of use_doy / use_abs_rel_enc / add_linear; not built: "
+            f"{bad or dict(conv_type=conv_type, agg_mode=agg_mode)}")
     if encoder:
         return_maps = True                      # utae.py:129-130
     if decoder_widths is None:
@@ -323,7 +368,9 @@ def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_con
                                 encoder_norm=encoder_norm, n_head=n_head, d_model=d_model, d_k=d_k,
                                 pad_value=float(pad_value), padding_mode=padding_mode, conv_type=conv_type,
                                 add_boundary_loss=bool(add_boundary_loss), encoder=bool(encoder),
-                                return_maps=bool(return_maps))
+                                return_maps=bool(return_maps), pe_mode=_pe_mode(use_abs_rel_enc, use_doy, add_linear),
+                                num_queries=int(num_queries))
+    self.use_abs_rel_enc, self.use_doy, self.add_linear, self.num_queries = use_abs_rel_enc, use_doy, add_linear, num_queries
     self.add_boundary_loss = bool(add_boundary_loss)
     return decoder_widths
 
@@ -361,7 +408,7 @@ class UTAE(_Backbone):
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
                                        padding_mode, conv_type=conv_type)
         self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
-        self.temporal_encoder = LTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
+        self.temporal_encoder = LTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k, use_abs_rel_enc=use_abs_rel_enc, num_queries=num_queries, use_doy=use_doy, add_linear=add_linear)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
         self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
         if add_boundary_loss:                                           # utae.py:195-198
@@ -389,7 +436,7 @@ class TimeUNet_v1(_Backbone):
                                        padding_mode, conv_type=conv_type)
         self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
         self.temporal_encoder = LTAE(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
-                                     mlp=[d_model, encoder_widths[0]])
+                                     mlp=[d_model, encoder_widths[0]], use_abs_rel_enc=use_abs_rel_enc, num_queries=num_queries, use_doy=use_doy, add_linear=add_linear)
         self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
 
 
@@ -413,7 +460,7 @@ class WTAE(_Backbone):
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
                                        padding_mode, conv_type=conv_type)
         self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
-        self.temporal_encoder = LTAE4WTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k)
+        self.temporal_encoder = LTAE4WTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k, use_abs_rel_enc=use_abs_rel_enc, num_queries=num_queries, use_doy=use_doy, add_linear=add_linear)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
         self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
         if add_boundary_loss:                                           # wtae.py:215-218

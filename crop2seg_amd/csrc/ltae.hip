@@ -2831,6 +2831,11 @@ extern "C" int c2s_ltae_uses_streaming(const c2s_ltae_desc* d) {
     return d && check(d) == C2S_OK && (use_stream(d) || use_reg_fwd(d)) ? 1 : 0;
 }
 
+extern "C" int c2s_ltae_fwd_path(const c2s_ltae_desc* d) {
+    if (!d || check(d) != C2S_OK) return -1;
+    return use_reg_fwd(d) ? 2 : (use_stream(d) ? 1 : 0);
+}
+
 extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                                     const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
                                     const int* valid, float* attn, float* attn_pre, float* emb, float* stats,

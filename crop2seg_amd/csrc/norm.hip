@@ -510,8 +510,19 @@ __device__ __forceinline__ OnepassItem onepass_item(long v, const c2s_norm_desc&
 
 // NK = float4 per lane: every segment is exactly NK*256 floats; a group is one wave or a whole number of workgroups
 // (the host checks both), so the four waves of a workgroup always work on one group.
+// Software pipeline: the loads of the workgroup's NEXT position are issued before the group of the current one meets, so a
+// wave always has a segment in flight while it waits (two register sets A / B, loop unrolled by two).
+template <int NK>
+struct OpSlot {
+    f32x4 xv[NK];
+    long v, row;
+    size_t base;
+    int grp, w, seg;
+    bool live, ok;
+};
+
 template <int NK, bool RES>
-__global__ __launch_bounds__(256, 4) void norm_onepass_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void norm_onepass_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ rmean,
                                                                float* __restrict__ rvar, long long* __restrict__ nbt,
                                                                float* __restrict__ gstats, float* __restrict__ row_ab,
@@ -532,54 +543,64 @@ __global__ __launch_bounds__(256, 4) void norm_onepass_fwd_kernel(const float* _
     const int wpg = (batch ? d.N : cpg) * segs;
     constexpr int L = NK * 256;
     const long quads = (nitems + 3) >> 2;
-    int par = 0;
-    for (long q = blockIdx.x; q < quads; q += gridDim.x, par ^= 1) {
-        const long v = q * 4 + wave;
-        const bool live = v < nitems;                              // only a single-wave-group launch has a ragged last quad
-        const OnepassItem it = onepass_item(live ? v : nitems - 1, d, segs);
-        const long row = it.row;
-        const int n = (int)(row / C), c = (int)(row % C);
-        const size_t base = (size_t)row * HW + (size_t)it.seg * L;
-        const bool ok = valid == nullptr || valid[n] != 0;       // BATCH launches come without flags (host check)
-        if (!ok) {                                               // uniform over the workgroup when it meets (wpg % 4 == 0)
-            if (live) {
-                if (it.seg == 0 && lane == 0) {
-                    row_ab[row * 3] = 0.f; row_ab[row * 3 + 1] = 0.f; row_ab[row * 3 + 2] = 0.f;
-                    if (c % cpg == 0) { gstats[it.grp * 2] = 0.f; gstats[it.grp * 2 + 1] = 0.f; }
+
+    // position q of this workgroup -> slot: item, flags, loads of the segment in flight
+    auto fetch = [&](OpSlot<NK>& s, long q) {
+        s.v = q * 4 + wave;
+        s.live = s.v < nitems;                                   // only a single-wave-group launch has a ragged last quad
+        const OnepassItem it = onepass_item(s.live ? s.v : nitems - 1, d, segs);
+        s.row = it.row; s.grp = it.grp; s.w = it.w; s.seg = it.seg;
+        s.base = (size_t)it.row * HW + (size_t)it.seg * L;
+        s.ok = valid == nullptr || valid[(int)(it.row / C)] != 0;       // BATCH launches come without flags (host check)
+        if (s.live && s.ok) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) s.xv[k] = *reinterpret_cast<const f32x4*>(x + s.base + lane * 4 + 256 * k);
+        }
+    };
+    // partial sums of the slot's segment, published for the group
+    auto reduce_publish = [&](OpSlot<NK>& s, float& pmean, float& m2) {
+        pmean = 0.f; m2 = 0.f;
+        if (!(s.live && s.ok)) return;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) t += (s.xv[k].x + s.xv[k].y) + (s.xv[k].z + s.xv[k].w);
+        t = wave_sum(t);
+        pmean = t / (float)L;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float a = s.xv[k].x - pmean, b = s.xv[k].y - pmean, cc = s.xv[k].z - pmean, dd = s.xv[k].w - pmean;
+            m2 += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+        m2 = wave_sum(m2);
+        if (wpg > 1) onepass_publish(sv, s.v, epoch, pmean, m2, lane);
+    };
+    // the group meets (wave 0 sweeps), then the slot's segment is normalised from registers and stored
+    auto finish = [&](OpSlot<NK>& s, float pmean, float m2, int par) {
+        const int c = (int)(s.row % C);
+        if (!s.ok) {                                             // uniform over the workgroup when it meets (wpg % 4 == 0)
+            if (s.live) {
+                if (s.seg == 0 && lane == 0) {
+                    row_ab[s.row * 3] = 0.f; row_ab[s.row * 3 + 1] = 0.f; row_ab[s.row * 3 + 2] = 0.f;
+                    if (c % cpg == 0) { gstats[s.grp * 2] = 0.f; gstats[s.grp * 2 + 1] = 0.f; }
                 }
                 f32x4 pv = {pad_value, pad_value, pad_value, pad_value};
 #pragma unroll
-                for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x4*>(y + base + lane * 4 + 256 * k) = pv;
+                for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x4*>(y + s.base + lane * 4 + 256 * k) = pv;
             }
-            continue;
+            return;
         }
-        f32x4 xv[NK], rv[RES ? NK : 1];
-        float pmean = 0.f, m2 = 0.f;
-        if (live) {
+        f32x4 rv[RES ? NK : 1];
+        if constexpr (RES) {
+            if (s.live) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) xv[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) s += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
-            s = wave_sum(s);
-            pmean = s / (float)L;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const float a = xv[k].x - pmean, b = xv[k].y - pmean, cc = xv[k].z - pmean, dd = xv[k].w - pmean;
-                m2 += (a * a + b * b) + (cc * cc + dd * dd);
-            }
-            m2 = wave_sum(m2);
-            if (wpg > 1) onepass_publish(sv, v, epoch, pmean, m2, lane);
-            if constexpr (RES) {                                 // in flight while the group meets
-#pragma unroll
-                for (int k = 0; k < NK; ++k) rv[k] = *reinterpret_cast<const f32x4*>(res + base + lane * 4 + 256 * k);
+                for (int k = 0; k < NK; ++k) rv[k] = *reinterpret_cast<const f32x4*>(res + s.base + lane * 4 + 256 * k);
             }
         }
         float mu, rstd, unb;
         bool leader;                                             // the wave that leaves the group's statistics behind
         if (wpg > 1) {
             if (wave == 0) {
-                onepass_sweep(sv, v - it.w, wpg, epoch, lane, poisoned, s_part[0], s_part[1]);
+                onepass_sweep(sv, s.v - s.w, wpg, epoch, lane, poisoned, s_part[0], s_part[1]);
                 // group_mean_rstd of the two-pass form on the swept partials (same order, same arithmetic)
                 double cnt = 0.0, sum = 0.0;
                 for (int w = lane; w < wpg; w += 64) { cnt += L; sum += (double)s_part[0][w] * L; }
@@ -596,43 +617,71 @@ __global__ __launch_bounds__(256, 4) void norm_onepass_fwd_kernel(const float* _
             }
             __syncthreads();
             if (wave != 0) { mu = s_stat[par][0]; rstd = s_stat[par][1]; unb = 0.f; }
-            leader = it.w == 0;                                  // wave 0 of the group's first workgroup
+            leader = s.w == 0;                                   // wave 0 of the group's first workgroup
         } else {
             const double var = (double)m2 / L;
             mu = pmean;
             rstd = (float)(1.0 / sqrt(var + (double)d.eps));
             unb = (float)(L > 1 ? (double)m2 / (L - 1.0) : var);
-            leader = live;
+            leader = s.live;
         }
-        if (!live) continue;
+        if (!s.live) return;
         if (leader && lane == 0) {
-            gstats[it.grp * 2] = mu; gstats[it.grp * 2 + 1] = rstd;
+            gstats[s.grp * 2] = mu; gstats[s.grp * 2 + 1] = rstd;
             if (batch && rmean != nullptr) {
-                rmean[it.grp] = (1.f - d.momentum) * rmean[it.grp] + d.momentum * mu;
-                rvar[it.grp] = (1.f - d.momentum) * rvar[it.grp] + d.momentum * unb;
+                rmean[s.grp] = (1.f - d.momentum) * rmean[s.grp] + d.momentum * mu;
+                rvar[s.grp] = (1.f - d.momentum) * rvar[s.grp] + d.momentum * unb;
             }
-            if (batch && it.grp == 0 && nbt != nullptr) *nbt += 1;
+            if (batch && s.grp == 0 && nbt != nullptr) *nbt += 1;
         }
         const float a = gamma[c] * rstd, b = beta[c];
-        if (it.seg == 0 && lane == 0) { row_ab[row * 3] = a; row_ab[row * 3 + 1] = b; row_ab[row * 3 + 2] = mu; }
+        if (s.seg == 0 && lane == 0) { row_ab[s.row * 3] = a; row_ab[s.row * 3 + 1] = b; row_ab[s.row * 3 + 2] = mu; }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = (xv[k][e] - mu) * a + b;
+                float t = (s.xv[k][e] - mu) * a + b;
                 if (relu) t = fmaxf(t, 0.f);
                 if constexpr (RES) t += rv[k][e];
                 o[e] = t;
             }
-            *reinterpret_cast<f32x4*>(y + base + lane * 4 + 256 * k) = o;
+            *reinterpret_cast<f32x4*>(y + s.base + lane * 4 + 256 * k) = o;
         }
+    };
+
+    OpSlot<NK> A, B;
+    long q = blockIdx.x;
+    if (q < quads) fetch(A, q);
+    while (q < quads) {
+        float pm, m2;
+        reduce_publish(A, pm, m2);
+        long qn = q + gridDim.x;
+        if (qn < quads) fetch(B, qn);
+        finish(A, pm, m2, 0);
+        q = qn;
+        if (q >= quads) break;
+        reduce_publish(B, pm, m2);
+        qn = q + gridDim.x;
+        if (qn < quads) fetch(A, qn);
+        finish(B, pm, m2, 1);
+        q = qn;
     }
     onepass_end(sv, epoch);
 }
 
 template <int NK>
-__global__ __launch_bounds__(256, 4) void norm_onepass_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+struct OpSlotB {
+    f32x4 xa[NK], ga[NK];
+    long v, row;
+    size_t base;
+    int grp, w, seg;
+    bool live, ok;
+};
+
+// backward: same pipeline (the next position's x and g are in flight while the group of the current one meets)
+template <int NK>
+__global__ __launch_bounds__(256) void norm_onepass_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                const float* __restrict__ row_ab,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ gstats, float* __restrict__ gx,
@@ -654,56 +703,64 @@ __global__ __launch_bounds__(256, 4) void norm_onepass_bwd_kernel(const float* _
     const int wpg = n_rows * segs;
     constexpr int L = NK * 256;
     const long quads = (nitems + 3) >> 2;
-    int par = 0;
-    for (long q = blockIdx.x; q < quads; q += gridDim.x, par ^= 1) {
-        const long v = q * 4 + wave;
-        const bool live = v < nitems;
-        const OnepassItem it = onepass_item(live ? v : nitems - 1, d, segs);
-        const long row = it.row;
-        const int nn = (int)(row / C), cc = (int)(row % C);
-        const size_t base = (size_t)row * HW + (size_t)it.seg * L;
-        const long item = row * segs + it.seg;
-        if (valid != nullptr && valid[nn] == 0) {                // uniform over the workgroup when it meets
-            if (live) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x4*>(gx + base + lane * 4 + 256 * k) = z;
-                if (lane == 0) { part[item * 3] = 0.f; part[item * 3 + 1] = 0.f; part[item * 3 + 2] = 0.f; }
-            }
-            continue;
-        }
-        f32x4 xa[NK], ga[NK];
-        const float mean = gstats[it.grp * 2], rstd = gstats[it.grp * 2 + 1];
-        const float a = row_ab[row * 3], b = row_ab[row * 3 + 1], mu = row_ab[row * 3 + 2];
-        float s1 = 0.f, s2 = 0.f;
-        if (live) {
+
+    auto fetch = [&](OpSlotB<NK>& s, long q) {
+        s.v = q * 4 + wave;
+        s.live = s.v < nitems;
+        const OnepassItem it = onepass_item(s.live ? s.v : nitems - 1, d, segs);
+        s.row = it.row; s.grp = it.grp; s.w = it.w; s.seg = it.seg;
+        s.base = (size_t)it.row * HW + (size_t)it.seg * L;
+        s.ok = valid == nullptr || valid[(int)(it.row / C)] != 0;
+        if (s.live && s.ok) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                xa[k] = *reinterpret_cast<const f32x4*>(x + base + lane * 4 + 256 * k);
-                ga[k] = *reinterpret_cast<const f32x4*>(g + base + lane * 4 + 256 * k);
+                s.xa[k] = *reinterpret_cast<const f32x4*>(x + s.base + lane * 4 + 256 * k);
+                s.ga[k] = *reinterpret_cast<const f32x4*>(g + s.base + lane * 4 + 256 * k);
             }
-#pragma unroll
-            for (int k = 0; k < NK; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xx = xa[k][e];
-                    const float gg = (!relu || (xx - mean) * a + b > 0.f) ? ga[k][e] : 0.f;
-                    ga[k][e] = gg;                                  // masked gradient, reused by the apply step
-                    s1 += gg;
-                    s2 += gg * ((xx - mean) * rstd);
-                }
-            s1 = wave_sum(s1); s2 = wave_sum(s2);
-            if (wpg > 1) onepass_publish(sv, v, epoch, s1, s2, lane);
-            if (lane == 0) { part[item * 3] = s1; part[item * 3 + 1] = s2; }     // for norm_bwd_params_kernel (a later launch)
         }
+    };
+    // masked gradient (kept in ga), partial sums s1 = sum g', s2 = sum g' xhat, published for the group
+    auto reduce_publish = [&](OpSlotB<NK>& s, float& s1, float& s2) {
+        s1 = 0.f; s2 = 0.f;
+        if (!(s.live && s.ok)) return;
+        const float mean = gstats[s.grp * 2], rstd = gstats[s.grp * 2 + 1];
+        const float a = row_ab[s.row * 3], b = row_ab[s.row * 3 + 1];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xx = s.xa[k][e];
+                const float gg = (!relu || (xx - mean) * a + b > 0.f) ? s.ga[k][e] : 0.f;
+                s.ga[k][e] = gg;
+                s1 += gg;
+                s2 += gg * ((xx - mean) * rstd);
+            }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (wpg > 1) onepass_publish(sv, s.v, epoch, s1, s2, lane);
+        const long item = s.row * segs + s.seg;
+        if (lane == 0) { part[item * 3] = s1; part[item * 3 + 1] = s2; }       // for norm_bwd_params_kernel (a later launch)
+    };
+    auto finish = [&](OpSlotB<NK>& s, float s1, float s2, int par) {
+        const int cc = (int)(s.row % C);
+        const long item = s.row * segs + s.seg;
+        if (!s.ok) {                                             // uniform over the workgroup when it meets
+            if (s.live) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x4*>(gx + s.base + lane * 4 + 256 * k) = z;
+                if (lane == 0) { part[item * 3] = 0.f; part[item * 3 + 1] = 0.f; part[item * 3 + 2] = 0.f; }
+            }
+            return;
+        }
+        const float rstd = gstats[s.grp * 2 + 1];
         float k2, k3;
         if (wpg > 1) {
             if (wave == 0) {
-                onepass_sweep(sv, v - it.w, wpg, epoch, lane, poisoned, s_part[0], s_part[1]);
+                onepass_sweep(sv, s.v - s.w, wpg, epoch, lane, poisoned, s_part[0], s_part[1]);
                 // the per-row sums over the segments run in the order of row_sums(): lanes over rows
                 double A = 0.0, Bv = 0.0, cnt = 0.0;
                 for (int r = lane; r < n_rows; r += 64) {
-                    const long rr = batch ? (long)r * C + it.grp : (long)it.grp * cpg + r;
+                    const long rr = batch ? (long)r * C + s.grp : (long)s.grp * cpg + r;
                     const float gm = gamma[rr % C];
                     double t1 = 0.0, t2 = 0.0;
                     for (int sg = 0; sg < segs; ++sg) { t1 += s_part[0][r * segs + sg]; t2 += s_part[1][r * segs + sg]; }
@@ -724,7 +781,8 @@ __global__ __launch_bounds__(256, 4) void norm_onepass_bwd_kernel(const float* _
             k2 = (float)(-(double)rstd * rstd * (gm * (double)s2) / (double)HW);
             k3 = (float)(-(double)rstd * (gm * (double)s1) / (double)HW);
         }
-        if (!live) continue;
+        if (!s.live) return;
+        const float mu = row_ab[s.row * 3 + 2];
         const float k1 = rstd * gamma[cc];
         float sdx = 0.f;
 #pragma unroll
@@ -732,13 +790,31 @@ __global__ __launch_bounds__(256, 4) void norm_onepass_bwd_kernel(const float* _
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = k1 * ga[k][e] + k2 * (xa[k][e] - mu) + k3;
+                o[e] = k1 * s.ga[k][e] + k2 * (s.xa[k][e] - mu) + k3;
                 sdx += o[e];
             }
-            *reinterpret_cast<f32x4*>(gx + base + lane * 4 + 256 * k) = o;
+            *reinterpret_cast<f32x4*>(gx + s.base + lane * 4 + 256 * k) = o;
         }
         sdx = wave_sum(sdx);
         if (lane == 0) part[item * 3 + 2] = sdx;
+    };
+
+    OpSlotB<NK> A, B;
+    long q = blockIdx.x;
+    if (q < quads) fetch(A, q);
+    while (q < quads) {
+        float s1, s2;
+        reduce_publish(A, s1, s2);
+        long qn = q + gridDim.x;
+        if (qn < quads) fetch(B, qn);
+        finish(A, s1, s2, 0);
+        q = qn;
+        if (q >= quads) break;
+        reduce_publish(B, s1, s2);
+        qn = q + gridDim.x;
+        if (qn < quads) fetch(A, qn);
+        finish(B, s1, s2, 1);
+        q = qn;
     }
     onepass_end(sv, epoch);
 }

@@ -32,9 +32,11 @@ _SIDE = None
 SIDE_WGRAD = _os.environ.get("C2S_WGRAD_STREAM", "1") != "0"
 SIDE_BATCH = int(_os.environ.get("C2S_WGRAD_BATCH", "8"))
 SIDE_FLUSH_POSITIONS = int(_os.environ.get("C2S_WGRAD_FLUSH_POSITIONS", str(1 << 19)))
-# While a hipGraph is being captured the fork / join events become cross-stream edges of the graph: the replayed step keeps
-# the two-stream overlap of the eager step.  C2S_GRAPH_SIDE=0 captures everything on one stream (round-2 behaviour).
-GRAPH_SIDE = _os.environ.get("C2S_GRAPH_SIDE", "1") != "0"
+# While a hipGraph is being captured the fork / join events become cross-stream edges of the graph.  Measured (round 3,
+# U-TAE B=4 T=32): the captured two-stream step replays at 17.1 ms against 12.65 ms for the single-stream capture and
+# 12.25 ms for eager two-stream launches -- the graph executor serialises around the cross-stream edges -- so a capture stays
+# on one stream unless C2S_GRAPH_SIDE=1.
+GRAPH_SIDE = _os.environ.get("C2S_GRAPH_SIDE", "0") != "0"
 
 
 def _side_ok() -> bool:
@@ -744,10 +746,16 @@ def positional_table(dates: Tensor, d: int, period: float) -> Tensor:
     return pe
 
 
+PE_MODES = {"rel": 0, "doy": 1, "abs_rel": 2, "linear": 3}
+
+
 def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor], prefix: str, n_head: int, d_k: int,
                    d_model: int, period: float, dropout_p: float, with_embedding: bool, seed: int,
-                   keep: Optional[Tensor], seed_dev: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor]:
-    """L-TAE steps 1-6 (reference tae.py:451-481, 738-847).  Returns (emb [B,d_model,h,w] | None, attn [H,B,T,h,w])."""
+                   keep: Optional[Tensor], seed_dev: Optional[Tensor] = None, pe_mode: str = "rel") -> Tuple[Optional[Tensor], Tensor]:
+    """L-TAE steps 1-6 (reference tae.py:451-481, 738-847).  Returns (emb [B,d_model,h,w] | None, attn [H,B,T,h,w]).
+    pe_mode: "rel" = the default sinusoid of the relative dates; "doy" / "abs_rel" / "linear" = the learnable encoders of
+    use_doy / use_abs_rel_enc (dates [B,T,2]) / add_linear (tae.py:404-430): the attention kernels then run with a zero
+    table and the general table enters next to them (csrc/ltae_pe.hip)."""
     B, T, Cc, h, w = x5.shape
     HW = h * w
     Q = ctx.p[prefix + ".attention_head.Q"]
@@ -757,14 +765,35 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     bc = ctx.p[prefix + ".inconv.bias"]
     gamma, beta = ctx.p[prefix + ".in_norm.weight"], ctx.p[prefix + ".in_norm.bias"]
     assert n_head == 16 and d_k == 4 and d_model == 256, "the fold kernels are built for n_head=16, d_k=4, d_model=256"
-    pe = positional_table(dates, d_model // n_head, period)
-    # parameter-only fold (DESIGN.md 3.2): U [16,C], s0 [B,T,16]; qwk is kept for the adjoint
+    mode = PE_MODES[pe_mode]
     dev = x5.device
+    pe256 = sin256 = d0 = d1 = None
+    if mode == 0:
+        pe = positional_table(dates, d_model // n_head, period)
+    else:
+        pe = ctx.ws.get("ltae_pe_zero", B * T * 16)
+        check(lib().c2s_fill(pe.data_ptr(), B * T * 16, 0.0, _stream()), "fill")
+        dl = dates.to(torch.int64)
+        d0 = (dl[..., 0] if mode == 2 else dl).contiguous()
+        d1 = dl[..., 1].contiguous() if mode == 2 else None
+        enc = prefix + (".positional_encoder_abs.fc" if mode == 2 else ".positional_encoder.fc")
+        peW, peb = ctx.p[enc + ".weight"], ctx.p[enc + ".bias"]
+        pe256 = torch.empty(B, T, d_model, device=dev, dtype=torch.float32)
+        sin256 = torch.empty(B, T, d_model, device=dev, dtype=torch.float32) if mode == 3 else None
+        bad = ctx.ws.bufs.get("ltae_pe_bad")
+        if bad is None:
+            bad = ctx.ws.bufs["ltae_pe_bad"] = torch.zeros(1, device=dev, dtype=torch.int32)
+        check(lib().c2s_ltae_pe_table(mode, d0.data_ptr(), _ptr(d1), float(period), peW.data_ptr(), peb.data_ptr(),
+                                      pe256.data_ptr(), _ptr(sin256), bad.data_ptr(), B * T, _stream()), "ltae_pe_table")
+    # parameter-only fold (DESIGN.md 3.2): U [16,C], s0 [B,T,16]; qwk is kept for the adjoint
     U = torch.empty(n_head, Cc, device=dev, dtype=torch.float32)
     s0 = torch.empty(B, T, n_head, device=dev, dtype=torch.float32)
     qwk = torch.empty(n_head, d_model, device=dev, dtype=torch.float32)
     check(lib().c2s_ltae_fold_fwd(Q.data_ptr(), Wk.data_ptr(), bk.data_ptr(), Wc3.data_ptr(), bc.data_ptr(), pe.data_ptr(),
                                   U.data_ptr(), s0.data_ptr(), qwk.data_ptr(), B * T, Cc, _stream()), "ltae_fold_fwd")
+    if mode != 0:
+        check(lib().c2s_ltae_pe_fwd(qwk.data_ptr(), pe256.data_ptr(), None, s0.data_ptr(), None, B, T, HW, 0, _stream()),
+              "ltae_pe_fwd")
     Wc = Wc3.view(d_model, Cc)
     p_eff = dropout_p if ctx.training else 0.0
     d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None, _ptr(seed_dev))
@@ -786,6 +815,9 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     if timed:
         e1.record()
         prof["ltae_events"].append((e0, e1))
+    if mode != 0 and emb is not None:
+        check(lib().c2s_ltae_pe_fwd(None, pe256.data_ptr(), attn.data_ptr(), None, emb.data_ptr(), B, T, HW, 1, _stream()),
+              "ltae_pe_fwd")
     if ctx.tape is None:
         return emb, attn
     tape = ctx.tape
@@ -808,6 +840,11 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
         gbet, _ = ctx.grad_sink(prefix + ".in_norm.bias")
         nws = lib().c2s_ltae_bwd_workspace_floats(C.byref(d))
         ws = ctx.ws.get("ltae", nws)
+        if mode != 0 and g_emb is not None:          # the positional part of the values: g_a += <g_emb_h, pe_h>
+            g_tot = torch.empty_like(attn)
+            check(lib().c2s_ltae_pe_gattn(g_emb.data_ptr(), pe256.data_ptr(), _ptr(g_attn), g_tot.data_ptr(), B, T, HW,
+                                          _stream()), "ltae_pe_gattn")
+            g_attn = g_tot
         check(lib().c2s_ltae_attn_bwd(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
                                       s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
                                       attn.data_ptr(), attn_pre.data_ptr(), stats.data_ptr(), _ptr(g_emb), _ptr(g_attn),
@@ -824,6 +861,14 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
                                       gWc.data_ptr() if emb is not None else None, gbc.data_ptr() if emb is not None else None,
                                       *[t.data_ptr() for t, _ in sinks], B * T, Cc, acc_mask, fbw.data_ptr(), fbw.numel(),
                                       _stream()), "ltae_fold_bwd")
+        if mode != 0:
+            g_pe = torch.empty(B, T, d_model, device=dev, dtype=torch.float32)
+            gW, _ = ctx.grad_sink(enc + ".weight")
+            gb, _ = ctx.grad_sink(enc + ".bias")
+            check(lib().c2s_ltae_pe_bwd(mode, d0.data_ptr(), _ptr(d1), Q.data_ptr(), Wk.data_ptr(), qwk.data_ptr(),
+                                        pe256.data_ptr(), _ptr(sin256), attn.data_ptr(), _ptr(g_emb), gs0.data_ptr(),
+                                        g_pe.data_ptr(), sinks[1][0].data_ptr(), sinks[0][0].data_ptr(), gW.data_ptr(),
+                                        gb.data_ptr(), B, T, HW, _stream()), "ltae_pe_bwd")
         tape.add_grad(x5, gx)
 
     tape.record(bwd)

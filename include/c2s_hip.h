@@ -294,6 +294,10 @@ int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* ga
  * a workspace and attn_pre; backward: additionally needs g_emb), 0 for the 16-/8-pixel LDS kernels.  Lets tests assert
  * which path they cover. */
 int c2s_ltae_uses_streaming(const c2s_ltae_desc* d);
+/* Which forward kernel c2s_ltae_attn_fwd_ws launches for this shape: 0 = the 16-pixel LDS kernel (ltae_fwd_kernel: small maps),
+ * 1 = the three-pass streaming kernels (ltae_prep + ltae_stream_fwd), 2 = the register-resident kernel (ltae_reg_fwd_kernel);
+ * -1 = bad descriptor.  (Measurement harnesses label their numbers with it.) */
+int c2s_ltae_fwd_path(const c2s_ltae_desc* d);
 size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
 /* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],
  * gU [16,C], gs0 [B,T,16], gWc [256,C] (embedding path only), gbc [256], ggamma [C], gbeta [C]. */
@@ -317,6 +321,29 @@ int c2s_ltae_fold_bwd(const float* Q, const float* Wk, const float* bk, const fl
                       float* gQ, float* gWk, float* gbk, float* gWc, float* gbc, int BT, int C, int acc_mask,
                       float* workspace, size_t ws_floats, void* stream);
 size_t c2s_ltae_fold_bwd_workspace_floats(void);
+
+/* Learnable positional encoders of the L-TAE (constructor flags use_doy / use_abs_rel_enc / add_linear: tae.py:404-430,
+ * 467-479; positional_encoding.py:7-73).  The attention kernels above keep running with a ZERO table pe[BT,16]; the general
+ * table pe256 [B,T,256] enters next to them (ltae_pe.hip):
+ *   c2s_ltae_pe_table : mode 1 (use_doy): pe256[bt,16h+j] = W[j,dates0] + b[j], W [16,365];  mode 2 (use_abs_rel_enc):
+ *                       sinusoid(dates0)[j] + W[j,dates1] + b[j];  mode 3 (add_linear): W [256,256] applied to the tiled
+ *                       sinusoid, which is saved in sin256 [BT,256] for the adjoint.  *bad_days counts days outside [0,365)
+ *                       (the reference's one_hot raises on them; here they are clamped).
+ *   c2s_ltae_pe_fwd   : phase 0, before c2s_ltae_attn_fwd: s0[bt,h] += qwk[h,:] . pe256[bt,:];  phase 1, after it:
+ *                       emb[b,16h+j,p] += sum_t attn[h,b,t,p] pe256[b,t,16h+j]   (emb may be NULL: W-TAE)
+ *   c2s_ltae_pe_gattn : g_attn_out = g_attn_in (or 0) + <g_emb_h, pe256_h>: the upstream gradient c2s_ltae_attn_bwd takes
+ *   c2s_ltae_pe_bwd   : after c2s_ltae_attn_bwd and c2s_ltae_fold_bwd: g_pe [BT,256] (scratch output), the pe part of
+ *                       d fc1_k.weight / d Q ACCUMULATED into gWk / gQ, and the encoder's parameter gradients gW, gb. */
+int c2s_ltae_pe_table(int mode, const long long* dates0, const long long* dates1, float period, const float* W, const float* b,
+                      float* pe256, float* sin256, int* bad_days, int BT, void* stream);
+int c2s_ltae_pe_fwd(const float* qwk, const float* pe256, const float* attn, float* s0, float* emb, int B, int T, int HW,
+                    int phase, void* stream);
+int c2s_ltae_pe_gattn(const float* g_emb, const float* pe256, const float* g_attn_in, float* g_attn_out, int B, int T, int HW,
+                      void* stream);
+int c2s_ltae_pe_bwd(int mode, const long long* dates0, const long long* dates1, const float* Q, const float* Wk,
+                    const float* qwk, const float* pe256, const float* sin256, const float* attn, const float* g_emb,
+                    const float* gs0, float* g_pe, float* gWk, float* gQ, float* gW, float* gb, int B, int T, int HW,
+                    void* stream);
 
 /* L-TAE tail (tae.py:442-449,486-488).  Linear(256,C') is a 1x1 convolution on the NCHW embedding
  * (c2s_conv_igemm), BatchNorm1d over P is c2s_norm_* with kind BATCH; the two pieces below are the rest:

@@ -62,10 +62,26 @@ class BackboneConfig:
     add_boundary_loss: bool = False          # second head boundary_conv = ConvBlock([dec0, 32, 2]) (utae.py:195-198)
     boundary_gamma: float = 2.0              # FocalCELoss(gamma=2.0) (src/learning/utils.py:259)
     pe_period: float = 1000.0                # PositionalEncoder T (positional_encoding.py:11)
+    # positional encoder of the L-TAE (tae.py:404-430): "rel" sinusoid of the relative dates (default); "doy" =
+    # AbsolutePositionalEncoder on the day of year (use_doy); "abs_rel" = sinusoid(dates[...,0]) + absolute(dates[...,1])
+    # (use_abs_rel_enc, dates [B,T,2]); "linear" = Linear(256,256) on the tiled sinusoid (add_linear)
+    pe_mode: str = "rel"
+    # the reference's constructor flags for the same thing (fixtures store constructor kwargs): resolved into pe_mode
+    use_doy: bool = False
+    use_abs_rel_enc: bool = False
+    add_linear: bool = False
     attn_dropout: float = 0.1                # tae.py:816
     mlp_dropout: float = 0.2                 # tae.py:361
     bn_momentum: float = 0.1
     eps: float = 1e-5
+
+    def __post_init__(self) -> None:
+        if self.use_abs_rel_enc:
+            self.pe_mode = "abs_rel"
+        elif self.add_linear:
+            self.pe_mode = "linear"      # with or without use_doy (tae.py:405-409,414-417)
+        elif self.use_doy:
+            self.pe_mode = "doy"
 
 
 class BNState:
@@ -236,6 +252,30 @@ def positional_table(dates: Tensor, d: int, period: float, repeat: int, dtype=to
     return out.repeat(1, 1, repeat).to(dtype)
 
 
+def absolute_table(doy: Tensor, w: Tensor, b: Tensor, repeat: int) -> Tensor:
+    """AbsolutePositionalEncoder (positional_encoding.py:46-73): one_hot(day of year, 365) -> Linear(365, d) -> tiled."""
+    oh = F.one_hot(doy.to(torch.int64), num_classes=365).to(w.dtype)       # [B,T,365]
+    return F.linear(oh, w, b).repeat(1, 1, repeat)
+
+
+def positional_encoding(dates: Tensor, sd: State, prefix: str, cfg: BackboneConfig, dtype=torch.float32) -> Tensor:
+    """The positional term of LTAE.forward (tae.py:404-430,467-479) for the four encoder configurations, [B,T,d_model]."""
+    H, dm = cfg.n_head, cfg.d_model
+    mode = getattr(cfg, "pe_mode", "rel")
+    if mode == "rel":
+        return positional_table(dates, dm // H, cfg.pe_period, H, dtype)
+    if mode == "doy":
+        return absolute_table(dates, sd[prefix + ".positional_encoder.fc.weight"], sd[prefix + ".positional_encoder.fc.bias"], H)
+    if mode == "abs_rel":
+        return (positional_table(dates[..., 0], dm // H, cfg.pe_period, H, dtype)
+                + absolute_table(dates[..., 1], sd[prefix + ".positional_encoder_abs.fc.weight"],
+                                 sd[prefix + ".positional_encoder_abs.fc.bias"], H))
+    if mode == "linear":
+        tab = positional_table(dates, dm // H, cfg.pe_period, H, dtype)
+        return F.linear(tab, sd[prefix + ".positional_encoder.fc.weight"], sd[prefix + ".positional_encoder.fc.bias"])
+    raise ValueError(mode)
+
+
 def ltae_attention(x: Tensor, dates: Tensor, pad_mask: Optional[Tensor], sd: State, prefix: str,
                    cfg: BackboneConfig, attn_keep: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
     """Steps 1-6 of LTAE.forward (tae.py:451-481) + LightweightMultiHeadAttention (tae.py:738-807)
@@ -251,7 +291,7 @@ def ltae_attention(x: Tensor, dates: Tensor, pad_mask: Optional[Tensor], sd: Sta
     seq = F.group_norm(seq, H, sd[prefix + ".in_norm.weight"], sd[prefix + ".in_norm.bias"], cfg.eps)
     e = F.conv1d(seq, sd[prefix + ".inconv.weight"], sd[prefix + ".inconv.bias"])   # [P,dm,T] (tae.py:464)
     e = e.permute(0, 2, 1)                                                 # [P,T,dm]
-    pe = positional_table(dates, dm // H, cfg.pe_period, H, e.dtype)       # [B,T,dm] (tae.py:476-479)
+    pe = positional_encoding(dates, sd, prefix, cfg, e.dtype)              # [B,T,dm] (tae.py:467-479)
     e = (e.view(B, h * w, T, dm) + pe[:, None]).view(P, T, dm)
     k = F.linear(e, sd[prefix + ".attention_head.fc1_k.weight"], sd[prefix + ".attention_head.fc1_k.bias"])
     k = k.view(P, T, H, dk)                                                # tae.py:768

@@ -90,3 +90,12 @@ def make_inputs(B: int, T: int, C: int, H: int, W: int, seed: int, lengths: Sequ
             dates[b, L:] = 0
     y = torch.randint(0, n_classes, (B, H, W), generator=g)
     return x, dates, y
+
+
+def dates_for(dates: torch.Tensor, ctor: dict) -> torch.Tensor:
+    """batch_positions as the positional-encoder flags of a fixture expect them: use_abs_rel_enc takes [B,T,2] = (relative
+    date, day of year); the day of year is a fixed function of the relative date here (padded frames keep 0)."""
+    if ctor and ctor.get("use_abs_rel_enc"):
+        doy = torch.where(dates > 0, (3 * dates + 17) % 365, torch.zeros_like(dates))
+        return torch.stack([dates, doy], dim=-1)
+    return dates

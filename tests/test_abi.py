@@ -97,7 +97,34 @@ def test_offdefault_flags_fail_loudly():
     with pytest.raises(NotImplementedError):
         C2S.WTAE(input_dim=10, agg_mode="max")
     with pytest.raises(NotImplementedError):
-        C2S.UTAE(input_dim=10, num_queries=2)
+        C2S.UTAE(input_dim=10, add_squeeze_excit=True)
+    with pytest.raises(NotImplementedError):
+        C2S.UTAE(input_dim=10, use_abs_rel_enc=True, use_doy=True)
+
+
+def test_positional_encoder_flags_extend_the_state_dict_like_the_reference():
+    """use_doy / use_abs_rel_enc / add_linear (tae.py:404-430): the encoder's parameters sit between inconv and the attention
+    head, as in the reference's constructor; num_queries > 1 is accepted (Q [16,n,4]) and the forward raises as the
+    reference's own forward does."""
+    import crop2seg_amd as C2S
+    base = list(C2S.UTAE(input_dim=10).state_dict())
+    at = base.index("temporal_encoder.inconv.bias") + 1
+    for kw, extra in ((dict(use_doy=True), [("temporal_encoder.positional_encoder.fc.weight", (16, 365)),
+                                            ("temporal_encoder.positional_encoder.fc.bias", (16,))]),
+                      (dict(use_abs_rel_enc=True), [("temporal_encoder.positional_encoder_abs.fc.weight", (16, 365)),
+                                                    ("temporal_encoder.positional_encoder_abs.fc.bias", (16,))]),
+                      (dict(add_linear=True), [("temporal_encoder.positional_encoder.fc.weight", (256, 256)),
+                                               ("temporal_encoder.positional_encoder.fc.bias", (256,))]),
+                      (dict(add_linear=True, use_doy=True), [("temporal_encoder.positional_encoder.fc.weight", (256, 256)),
+                                                             ("temporal_encoder.positional_encoder.fc.bias", (256,))])):
+        for cls in (C2S.UTAE, C2S.WTAE, C2S.TimeUNet_v1):
+            sd = cls(input_dim=10, **kw).state_dict()
+            b0 = list(cls(input_dim=10).state_dict())
+            i = b0.index("temporal_encoder.inconv.bias") + 1
+            assert list(sd) == b0[:i] + [k for k, _ in extra] + b0[i:], (cls.__name__, kw)
+            assert all(tuple(sd[k].shape) == s for k, s in extra)
+    net = C2S.UTAE(input_dim=10, num_queries=2)
+    assert tuple(net.state_dict()["temporal_encoder.attention_head.Q"].shape) == (16, 2, 4)
 
 
 def test_optional_heads_extend_the_state_dict_like_the_reference():
