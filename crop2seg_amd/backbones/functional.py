@@ -43,6 +43,7 @@ class BackboneSpec:
     pe_period: float = 1000.0
     pe_mode: str = "rel"              # "doy" / "abs_rel" / "linear": the learnable positional encoders (tae.py:404-430)
     num_queries: int = 1              # > 1: accepted by the constructors, the forward raises as the reference's does
+    add_squeeze_excit: bool = False   # SqueezeAndExcitation after in_conv and after every encoder down block (utae.py:145,159)
     attn_dropout: float = 0.1       # reference tae.py:816
     mlp_dropout: float = 0.2        # reference tae.py:361
 
@@ -69,9 +70,10 @@ def _norm_kind(norm: str) -> int:
 
 def conv_layer(ctx: E.Ctx, srcs: Sequence[Tensor], prefix: str, n_convs: int, norm: str, k: int, s: int, p: int,
                spec: BackboneSpec, valid: Optional[Tensor], residual: Optional[Tensor] = None,
-               depthwise_separable: bool = False, need_input_grad: bool = True) -> Tensor:
+               depthwise_separable: bool = False, need_input_grad: bool = True, add_squeeze: bool = False) -> Tensor:
     """ConvLayer: [conv -> norm -> ReLU] * n_convs (reference conv.py:29-96); the optional residual is added
-    after the last ReLU (conv.py:292,410)."""
+    after the last ReLU (conv.py:292,410); add_squeeze appends SqueezeAndExcitation at Sequential index 3*n_convs
+    (conv.py:90-91)."""
     mode = _mode(spec)
     x = list(srcs)
     y = None
@@ -91,22 +93,27 @@ def conv_layer(ctx: E.Ctx, srcs: Sequence[Tensor], prefix: str, n_convs: int, no
                        residual if last else None, valid, spec.pad_value if valid is not None else 0.0, conv_bias=bias,
                        affine=norm != "instance")
         x = [y]
+    if add_squeeze:
+        y = E.squeeze_excite(ctx, y, f"{prefix}.conv.{3 * n_convs}", valid, spec.pad_value if valid is not None else 0.0)
     return y
 
 
-def conv_block(ctx, x, prefix, n_convs, norm, spec, valid, need_input_grad=True, depthwise_separable=False):
+def conv_block(ctx, x, prefix, n_convs, norm, spec, valid, need_input_grad=True, depthwise_separable=False, add_squeeze=False):
     """ConvBlock (reference conv.py:168-200)."""
     return conv_layer(ctx, [x], prefix + ".conv", n_convs, norm, 3, 1, 1, spec, valid, need_input_grad=need_input_grad,
-                      depthwise_separable=depthwise_separable)
+                      depthwise_separable=depthwise_separable, add_squeeze=add_squeeze)
 
 
-def down_conv_block(ctx, x, prefix, norm, spec, valid, depthwise_separable=False):
-    """DownConvBlock (reference conv.py:238-296): down -> conv1 -> out + conv2(out)."""
+def down_conv_block(ctx, x, prefix, norm, spec, valid, depthwise_separable=False, add_squeeze=False):
+    """DownConvBlock (reference conv.py:238-296): down -> conv1 -> out + conv2(out) (-> sae, conv.py:294)."""
     o = conv_layer(ctx, [x], prefix + ".down", 1, norm, spec.str_conv_k, spec.str_conv_s, spec.str_conv_p, spec, valid,
                    depthwise_separable=depthwise_separable)
     o1 = conv_layer(ctx, [o], prefix + ".conv1", 1, norm, 3, 1, 1, spec, valid, depthwise_separable=depthwise_separable)
-    return conv_layer(ctx, [o1], prefix + ".conv2", 1, norm, 3, 1, 1, spec, valid, residual=o1,
-                      depthwise_separable=depthwise_separable)
+    o2 = conv_layer(ctx, [o1], prefix + ".conv2", 1, norm, 3, 1, 1, spec, valid, residual=o1,
+                    depthwise_separable=depthwise_separable)
+    if add_squeeze:
+        o2 = E.squeeze_excite(ctx, o2, prefix + ".sae", valid, spec.pad_value if valid is not None else 0.0)
+    return o2
 
 
 def up_conv_block(ctx, x, skip, prefix, spec):
@@ -176,11 +183,13 @@ def utae_forward(ctx, spec, x5, dates, drop):
     B, T = x5.shape[:2]
     valid = E.frame_flags(x5, spec.pad_value)
     dws = spec.conv_type == "depthwise_separable"
-    f = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws)
+    se = spec.add_squeeze_excit
+    f = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws,
+                   add_squeeze=se)
     fmaps = [f]
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):
-        f = down_conv_block(ctx, f, f"down_blocks.{i}", spec.encoder_norm, spec, valid, depthwise_separable=dws)
+        f = down_conv_block(ctx, f, f"down_blocks.{i}", spec.encoder_norm, spec, valid, depthwise_separable=dws, add_squeeze=se)
         fmaps.append(f)
     out, att = ltae(ctx, _unfold(fmaps[-1], B, T), dates, valid, "temporal_encoder", spec, drop, True)
     skips = [E.temporal_aggregate(ctx, _unfold(fmaps[-(i + 2)], B, T), att, valid, spec.n_head, spec.agg_mode)
@@ -193,12 +202,15 @@ def timeunet_forward(ctx, spec, x5, dates, drop):
     B, T = x5.shape[:2]
     valid = E.frame_flags(x5, spec.pad_value)
     dws = spec.conv_type == "depthwise_separable"
-    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws)
+    se = spec.add_squeeze_excit
+    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws,
+                    add_squeeze=se)
     out, att = ltae(ctx, _unfold(f0, B, T), dates, valid, "temporal_encoder", spec, drop, True)
     fmaps = [out]
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):
-        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None, depthwise_separable=dws))
+        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None, depthwise_separable=dws,
+                                     add_squeeze=se))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(ctx, fmaps[-1], skips, spec, att)
 
@@ -208,15 +220,19 @@ def wtae_forward(ctx, spec, x5, dates, drop):
     B, T = x5.shape[:2]
     valid = E.frame_flags(x5, spec.pad_value)
     dws = spec.conv_type == "depthwise_separable"
-    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws)
+    se = spec.add_squeeze_excit
+    f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws,
+                    add_squeeze=se)
     red = f0
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):
-        red = down_conv_block(ctx, red, f"spatial_reduction.{i}", spec.encoder_norm, spec, valid, depthwise_separable=True)
+        red = down_conv_block(ctx, red, f"spatial_reduction.{i}", spec.encoder_norm, spec, valid, depthwise_separable=True,
+                              add_squeeze=se)
     _, att = ltae(ctx, _unfold(red, B, T), dates, valid, "temporal_encoder", spec, drop, False)
     fmaps = [E.temporal_aggregate(ctx, _unfold(f0, B, T), att, valid, spec.n_head, spec.agg_mode)]
     for i in range(n_stages - 1):
-        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None, depthwise_separable=dws))
+        fmaps.append(down_conv_block(ctx, fmaps[-1], f"down_blocks.{i}", spec.encoder_norm, spec, None, depthwise_separable=dws,
+                                     add_squeeze=se))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(ctx, fmaps[-1], skips, spec, att)
 

@@ -674,6 +674,44 @@ def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: boo
     return y
 
 
+def squeeze_excite(ctx: Ctx, x: Tensor, prefix: str, valid: Optional[Tensor], pad_value: float = 0.0) -> Tensor:
+    """SqueezeAndExcitation (reference squeeze_and_excitation.py:7-30): x * sigmoid(W2 relu(W1 mean_hw(x))) per frame;
+    `prefix` names the module (its Linear layers are prefix.sae.1 and prefix.sae.3, bias-free)."""
+    W1, W2 = ctx.p[prefix + ".sae.1.weight"], ctx.p[prefix + ".sae.3.weight"]
+    N, Cc = x.shape[:2]
+    HW = x[0, 0].numel()
+    R = Cc // 16
+    assert tuple(W1.shape) == (R, Cc) and tuple(W2.shape) == (Cc, R), (prefix, W1.shape, W2.shape)
+    dev = x.device
+    pooled = torch.empty(N, Cc, device=dev, dtype=torch.float32)
+    hidden = torch.empty(N, R, device=dev, dtype=torch.float32)
+    scale = torch.empty(N, Cc, device=dev, dtype=torch.float32)
+    y = torch.empty_like(x)
+    nws = lib().c2s_se_workspace_floats(N, Cc, HW)
+    ws = ctx.ws.get("se", nws)
+    check(lib().c2s_se_fwd(x.data_ptr(), W1.data_ptr(), W2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(), scale.data_ptr(),
+                           y.data_ptr(), _ptr(valid), N, Cc, HW, float(pad_value), ws.data_ptr(), ws.numel(), _stream()), "se_fwd")
+    if ctx.tape is None:
+        return y
+    tape = ctx.tape
+    tape.track(y)
+
+    def bwd():
+        g = tape.pop_grad(y)
+        if g is None:
+            return
+        g1, a1 = ctx.grad_sink(prefix + ".sae.1.weight")
+        g2, a2 = ctx.grad_sink(prefix + ".sae.3.weight")
+        ws_ = ctx.ws.get("se", nws)
+        check(lib().c2s_se_bwd(x.data_ptr(), g.data_ptr(), W1.data_ptr(), W2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(),
+                               scale.data_ptr(), g.data_ptr(), g1.data_ptr(), g2.data_ptr(), a1, a2, _ptr(valid), N, Cc, HW,
+                               ws_.data_ptr(), ws_.numel(), _stream()), "se_bwd")
+        tape.add_grad(x, g)
+
+    tape.record(bwd)
+    return y
+
+
 # =================================================================================================
 # temporal aggregation
 # =================================================================================================

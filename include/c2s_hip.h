@@ -250,6 +250,19 @@ int c2s_norm_bwd_onepass(const c2s_norm_desc* d, const float* x, const float* g,
                          size_t sync_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Squeeze-and-excitation (squeeze_and_excitation.py:7-30; conv.py:90-91,286-294; constructor flag add_squeeze_excit):
+ *   y[n,c,:] = x[n,c,:] * sigmoid(W2 relu(W1 mean_hw(x[n])))[c],  W1 [C/16, C], W2 [C, C/16], no biases.
+ * c2s_se_fwd leaves pooled [N,C], hidden [N,C/16] (post-ReLU) and scale [N,C] for the backward; rows of padded frames are
+ * filled with pad_value.  c2s_se_bwd: gx (may alias g), gW1 / gW2 (acc_* != 0: accumulate).  16 <= C <= 1024.
+ * ------------------------------------------------------------------------------------------------ */
+size_t c2s_se_workspace_floats(int N, int C, int HW);
+int c2s_se_fwd(const float* x, const float* W1, const float* W2, float* pooled, float* hidden, float* scale, float* y,
+               const int* valid, int N, int C, int HW, float pad_value, float* workspace, size_t ws_floats, void* stream);
+int c2s_se_bwd(const float* x, const float* g, const float* W1, const float* W2, const float* pooled, const float* hidden,
+               const float* scale, float* gx, float* gW1, float* gW2, int acc_w1, int acc_w2, const int* valid, int N, int C,
+               int HW, float* workspace, size_t ws_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Frame flags: valid[n] = any(x[n] != pad_value)   (utae.py:201-203, temp_shared_block.py:31)
  * ------------------------------------------------------------------------------------------------ */
 int c2s_frame_flags(const float* x, int* valid, int N, long frame_elems, float pad_value, void* stream);

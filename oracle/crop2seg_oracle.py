@@ -70,6 +70,7 @@ class BackboneConfig:
     use_doy: bool = False
     use_abs_rel_enc: bool = False
     add_linear: bool = False
+    add_squeeze_excit: bool = False          # SqueezeAndExcitation after in_conv and the encoder down blocks (utae.py:145,159)
     attn_dropout: float = 0.1                # tae.py:816
     mlp_dropout: float = 0.2                 # tae.py:361
     bn_momentum: float = 0.1
@@ -152,9 +153,17 @@ def batch_norm(x: Tensor, sd: State, prefix: str, training: bool, cfg: BackboneC
     return out
 
 
+def squeeze_excite(x: Tensor, sd: State, prefix: str) -> Tensor:
+    """SqueezeAndExcitation.forward (squeeze_and_excitation.py:16-30): x * sigmoid(W2 relu(W1 mean_hw(x)))."""
+    y = x.mean(dim=(2, 3))
+    y = relu(F.linear(y, sd[prefix + ".sae.1.weight"]))
+    y = torch.sigmoid(F.linear(y, sd[prefix + ".sae.3.weight"]))
+    return x * y[:, :, None, None]
+
+
 def conv_layer(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, k: int, s: int, p: int,
                cfg: BackboneConfig, training: bool, bn: Optional[BNState],
-               depthwise_separable: bool = False) -> Tensor:
+               depthwise_separable: bool = False, add_squeeze: bool = False) -> Tensor:
     """ConvLayer: [conv -> norm -> ReLU] * n_convs; Sequential indices 3*i, 3*i+1
     (src/backbones/conv.py:29-96).  norm 'group' = GroupNorm(4 groups) (conv.py:42,56-60)."""
     for i in range(n_convs):
@@ -173,6 +182,8 @@ def conv_layer(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, k: in
         elif norm == "instance":
             x = F.instance_norm(x, eps=cfg.eps)
         x = relu(x)
+    if add_squeeze:                      # conv.py:90-91: appended once, after the last conv-norm-ReLU
+        x = squeeze_excite(x, sd, f"{prefix}.conv.{3 * n_convs}")
     return x
 
 
@@ -205,21 +216,25 @@ def shared_over_time(fn, x: Tensor, pad_value: Optional[float]) -> Tensor:
 
 
 def conv_block(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, cfg: BackboneConfig,
-               training: bool, bn: Optional[BNState], pad_value: Optional[float], depthwise_separable: bool = False) -> Tensor:
+               training: bool, bn: Optional[BNState], pad_value: Optional[float], depthwise_separable: bool = False,
+               add_squeeze: bool = False) -> Tensor:
     """ConvBlock (conv.py:168-200) applied through smart_forward."""
     return shared_over_time(
-        lambda z: conv_layer(z, sd, prefix + ".conv", n_convs, norm, 3, 1, 1, cfg, training, bn, depthwise_separable),
+        lambda z: conv_layer(z, sd, prefix + ".conv", n_convs, norm, 3, 1, 1, cfg, training, bn, depthwise_separable,
+                             add_squeeze),
         x, pad_value)
 
 
 def down_conv_block(x: Tensor, sd: State, prefix: str, norm: str, cfg: BackboneConfig, training: bool,
-                    bn: Optional[BNState], pad_value: Optional[float], depthwise_separable: bool = False) -> Tensor:
-    """DownConvBlock (conv.py:238-296): down(k,s,p) -> conv1 -> out + conv2(out)."""
+                    bn: Optional[BNState], pad_value: Optional[float], depthwise_separable: bool = False,
+                    add_squeeze: bool = False) -> Tensor:
+    """DownConvBlock (conv.py:238-296): down(k,s,p) -> conv1 -> out + conv2(out) (-> sae, conv.py:294)."""
     def fn(z: Tensor) -> Tensor:
         o = conv_layer(z, sd, prefix + ".down", 1, norm, cfg.str_conv_k, cfg.str_conv_s, cfg.str_conv_p,
                        cfg, training, bn, depthwise_separable)
         o = conv_layer(o, sd, prefix + ".conv1", 1, norm, 3, 1, 1, cfg, training, bn, depthwise_separable)
-        return o + conv_layer(o, sd, prefix + ".conv2", 1, norm, 3, 1, 1, cfg, training, bn, depthwise_separable)
+        o = o + conv_layer(o, sd, prefix + ".conv2", 1, norm, 3, 1, 1, cfg, training, bn, depthwise_separable)
+        return squeeze_excite(o, sd, prefix + ".sae") if add_squeeze else o
     return shared_over_time(fn, x, pad_value)
 
 
@@ -390,11 +405,12 @@ def utae_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, train
     """UTAE.forward (utae.py:200-252), default flags.  Returns (logits, attn)."""
     pad_mask = frame_pad_mask(x, cfg.pad_value)
     dws = cfg.conv_type == "depthwise_separable"
-    fmaps = [conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws)]
+    fmaps = [conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws,
+                    cfg.add_squeeze_excit)]
     n_stages = len(cfg.encoder_widths)
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(fmaps[-1], sd, f"down_blocks.{i}", cfg.encoder_norm, cfg, training, bn,
-                                     cfg.pad_value, dws))
+                                     cfg.pad_value, dws, cfg.add_squeeze_excit))
     out, att = ltae(fmaps[-1], dates, pad_mask, sd, "temporal_encoder", cfg, training, bn, attn_keep, mlp_keep)
     skips = [temporal_aggregate(fmaps[-(i + 2)], pad_mask, att, cfg.agg_mode) for i in range(n_stages - 1)]
     return _decoder_and_head(out, skips, sd, cfg, training, bn), att
@@ -407,13 +423,14 @@ def timeunet_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, t
     -> plain U-Net on the single aggregated image (down blocks see 4-D input)."""
     pad_mask = frame_pad_mask(x, cfg.pad_value)
     dws = cfg.conv_type == "depthwise_separable"
-    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws)
+    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws,
+                    cfg.add_squeeze_excit)
     out, att = ltae(f0, dates, pad_mask, sd, "temporal_encoder", cfg, training, bn, attn_keep, mlp_keep)
     fmaps = [out]
     n_stages = len(cfg.encoder_widths)
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(fmaps[-1], sd, f"down_blocks.{i}", cfg.encoder_norm, cfg, training, bn,
-                                     cfg.pad_value, dws))
+                                     cfg.pad_value, dws, cfg.add_squeeze_excit))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(fmaps[-1], skips, sd, cfg, training, bn), att
 
@@ -424,17 +441,18 @@ def wtae_forward(sd: State, x: Tensor, dates: Tensor, cfg: BackboneConfig, train
     attention masks (LTAE4WTAE) -> aggregate the full-resolution features -> plain U-Net."""
     pad_mask = frame_pad_mask(x, cfg.pad_value)
     dws = cfg.conv_type == "depthwise_separable"
-    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws)
+    f0 = conv_block(x, sd, "in_conv", 2, cfg.encoder_norm, cfg, training, bn, cfg.pad_value, dws,
+                    cfg.add_squeeze_excit)
     red = f0
     n_stages = len(cfg.encoder_widths)
     for i in range(n_stages - 1):
         red = down_conv_block(red, sd, f"spatial_reduction.{i}", cfg.encoder_norm, cfg, training, bn,
-                              cfg.pad_value, depthwise_separable=True)
+                              cfg.pad_value, depthwise_separable=True, add_squeeze=cfg.add_squeeze_excit)
     att = ltae_for_wtae(red, dates, pad_mask, sd, "temporal_encoder", cfg, attn_keep)
     fmaps = [temporal_aggregate(f0, pad_mask, att, cfg.agg_mode)]
     for i in range(n_stages - 1):
         fmaps.append(down_conv_block(fmaps[-1], sd, f"down_blocks.{i}", cfg.encoder_norm, cfg, training, bn,
-                                     cfg.pad_value, dws))
+                                     cfg.pad_value, dws, cfg.add_squeeze_excit))
     skips = [fmaps[-(i + 2)] for i in range(n_stages - 1)]
     return _decoder_and_head(fmaps[-1], skips, sd, cfg, training, bn), att
 

@@ -97,8 +97,6 @@ def test_offdefault_flags_fail_loudly():
     with pytest.raises(NotImplementedError):
         C2S.WTAE(input_dim=10, agg_mode="max")
     with pytest.raises(NotImplementedError):
-        C2S.UTAE(input_dim=10, add_squeeze_excit=True)
-    with pytest.raises(NotImplementedError):
         C2S.UTAE(input_dim=10, use_abs_rel_enc=True, use_doy=True)
 
 

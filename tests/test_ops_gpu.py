@@ -564,3 +564,35 @@ def test_pack_plan_matches_individual_packs():
     second = run()
     for a, b in zip(first, second):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,use_valid", [((4, 64, 32, 32), True), ((3, 128, 8, 8), False), ((2, 64, 128, 128), True),
+                                             ((2, 256, 6, 10), False)])
+def test_squeeze_excite_fwd_bwd(shape, use_valid):
+    """SqueezeAndExcitation (squeeze_and_excitation.py:7-30) forward and backward against torch autograd on the formula."""
+    E, L = _engine()
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(shape, generator=g).requires_grad_(True)
+    w1 = (torch.randn(C // 16, C, generator=g) * 0.3).requires_grad_(True)
+    w2 = (torch.randn(C, C // 16, generator=g) * 0.5).requires_grad_(True)
+    valid = torch.ones(N, dtype=torch.int32)
+    if use_valid:
+        valid[1] = 0
+    keep = valid.bool()
+    xs = x[keep]
+    s = torch.sigmoid(F.linear(F.relu(F.linear(xs.mean(dim=(2, 3)), w1)), w2))
+    y = xs * s[:, :, None, None]
+    gout = torch.randn(y.shape, generator=g)
+    y.backward(gout)
+    ctx = make_ctx({"m.sae.1.weight": w1.detach(), "m.sae.3.weight": w2.detach()})
+    xd = x.detach().cuda()
+    out = E.squeeze_excite(ctx, xd, "m", valid.cuda() if use_valid else None, 0.0)
+    assert rel(out[keep.cuda()], y) < 2e-6
+    if use_valid:
+        assert float(out[1].abs().max()) == 0.0
+    gfull = torch.zeros(shape)
+    gfull[keep] = gout
+    seed_backward(ctx, out, gfull)
+    assert rel(ctx.tape.grads[xd.data_ptr()][keep.cuda()], x.grad[keep]) < 5e-6
+    assert rel(ctx.g["m.sae.1.weight"], w1.grad) < 2e-5 and rel(ctx.g["m.sae.3.weight"], w2.grad) < 2e-5
