@@ -87,6 +87,7 @@ SIGNATURES = {
     "c2s_norm_fwd_onepass": (I, [C.POINTER(NormDesc), P, P, P, P, P, P, P, P, P, P, I, P, F, P, SZ, P]),
     "c2s_norm_bwd_onepass": (I, [C.POINTER(NormDesc), P, P, P, P, P, I, P, P, P, P, P, SZ, P, P, SZ, P]),
     "c2s_se_workspace_floats": (SZ, [I, I, I]),
+    "c2s_channel_bias_add": (I, [P, P, P, I, I, I, P]),
     "c2s_se_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, P, SZ, P]),
     "c2s_se_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, P, I, I, I, P, SZ, P]),
     "c2s_frame_flags": (I, [P, P, I, L, F, P]),

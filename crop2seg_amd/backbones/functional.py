@@ -44,6 +44,7 @@ class BackboneSpec:
     pe_mode: str = "rel"              # "doy" / "abs_rel" / "linear": the learnable positional encoders (tae.py:404-430)
     num_queries: int = 1              # > 1: accepted by the constructors, the forward raises as the reference's does
     add_squeeze_excit: bool = False   # SqueezeAndExcitation after in_conv and after every encoder down block (utae.py:145,159)
+    use_mbconv: bool = False          # MBConv blocks instead of the classical conv blocks (utae.py:118-122; mbconv.py)
     attn_dropout: float = 0.1       # reference tae.py:816
     mlp_dropout: float = 0.2        # reference tae.py:361
 
@@ -98,8 +99,47 @@ def conv_layer(ctx: E.Ctx, srcs: Sequence[Tensor], prefix: str, n_convs: int, no
     return y
 
 
+def _norm_groups(norm: str, channels: int) -> int:
+    return channels if norm == "instance" else 4
+
+
+def mbconv(ctx: E.Ctx, srcs: Sequence[Tensor], prefix: str, norm: str, spec: BackboneSpec, valid: Optional[Tensor],
+           need_input_grad: bool = True) -> Tensor:
+    """MBConv (reference mbconv.py:25-97): 1x1 expansion (x4) -> norm -> ReLU -> depthwise 3x3 (reflect, with bias) -> norm ->
+    ReLU -> SqueezeAndExcitation -> 1x1 projection -> norm (no ReLU), plus the input when in == out channels (ResidualAdd).
+    `prefix` names the MBConv; its inner Sequential is prefix.0.0.block with the residual, prefix.0.0.0 without."""
+    cin = sum(t.shape[1] for t in srcs)
+    res = (prefix + ".0.0.block.0.weight") in ctx.p
+    base = prefix + (".0.0.block" if res else ".0.0.0")
+    cout = ctx.p[base + ".7.weight"].shape[0]
+    assert res == (cin == cout) and (not res or len(srcs) == 1)
+    kind = _norm_kind(norm)
+    pv = spec.pad_value if valid is not None else 0.0
+    aff = norm != "instance"
+    o = E.conv2d(ctx, srcs, base + ".0.weight", base + ".0.bias", 1, 1, 0, _lib.PAD_ZEROS, valid, need_input_grad=need_input_grad)
+    o = E.norm_act(ctx, o, base + ".1", kind, _norm_groups(norm, o.shape[1]), True, None, valid, pv, conv_bias=base + ".0.bias",
+                   affine=aff)
+    o = E.depthwise_conv2d(ctx, o, base + ".3.weight", 3, 1, 1, _lib.PAD_REFLECT, valid, bname=base + ".3.bias")
+    o = E.norm_act(ctx, o, base + ".4", kind, _norm_groups(norm, o.shape[1]), True, None, valid, pv, conv_bias=base + ".3.bias",
+                   affine=aff)
+    o = E.squeeze_excite(ctx, o, base + ".6", valid, pv)
+    o = E.conv2d(ctx, [o], base + ".7.weight", base + ".7.bias", 1, 1, 0, _lib.PAD_ZEROS, valid)
+    return E.norm_act(ctx, o, base + ".8", kind, _norm_groups(norm, o.shape[1]), False, srcs[0] if res else None, valid, pv,
+                      conv_bias=base + ".7.bias", affine=aff)
+
+
+def mbconv_layer(ctx, srcs, prefix, n, norm, spec, valid, need_input_grad=True):
+    """MBConvLayer (reference mbconv.py:100-128): n MBConv blocks, prefix.conv.{i}."""
+    x = list(srcs)
+    for i in range(n):
+        x = [mbconv(ctx, x, f"{prefix}.conv.{i}", norm, spec, valid, need_input_grad=need_input_grad or i > 0)]
+    return x[0]
+
+
 def conv_block(ctx, x, prefix, n_convs, norm, spec, valid, need_input_grad=True, depthwise_separable=False, add_squeeze=False):
-    """ConvBlock (reference conv.py:168-200)."""
+    """ConvBlock (reference conv.py:168-200); with use_mbconv: MBConvBlock (mbconv.py:131-152)."""
+    if spec.use_mbconv:
+        return mbconv_layer(ctx, [x], prefix + ".conv", n_convs, norm, spec, valid, need_input_grad=need_input_grad)
     return conv_layer(ctx, [x], prefix + ".conv", n_convs, norm, 3, 1, 1, spec, valid, need_input_grad=need_input_grad,
                       depthwise_separable=depthwise_separable, add_squeeze=add_squeeze)
 
@@ -108,6 +148,9 @@ def down_conv_block(ctx, x, prefix, norm, spec, valid, depthwise_separable=False
     """DownConvBlock (reference conv.py:238-296): down -> conv1 -> out + conv2(out) (-> sae, conv.py:294)."""
     o = conv_layer(ctx, [x], prefix + ".down", 1, norm, spec.str_conv_k, spec.str_conv_s, spec.str_conv_p, spec, valid,
                    depthwise_separable=depthwise_separable)
+    if spec.use_mbconv:             # MBDownConvBlock (mbconv.py:155-198): down -> conv1 -> conv2, no outer residual, no sae
+        o1 = mbconv_layer(ctx, [o], prefix + ".conv1", 1, norm, spec, valid)
+        return mbconv_layer(ctx, [o1], prefix + ".conv2", 1, norm, spec, valid)
     o1 = conv_layer(ctx, [o], prefix + ".conv1", 1, norm, 3, 1, 1, spec, valid, depthwise_separable=depthwise_separable)
     o2 = conv_layer(ctx, [o1], prefix + ".conv2", 1, norm, 3, 1, 1, spec, valid, residual=o1,
                     depthwise_separable=depthwise_separable)
@@ -125,6 +168,9 @@ def up_conv_block(ctx, x, skip, prefix, spec):
     assert spec.str_conv_k == 4 and spec.str_conv_s == 2 and spec.str_conv_p == 1, "only k=4,s=2,p=1 up-convs are built"
     up = E.conv_transpose2d(ctx, x, prefix + ".up.0.weight", prefix + ".up.0.bias")
     up = E.norm_act(ctx, up, prefix + ".up.1", _lib.NORM_BATCH, 1, True, None, None, conv_bias=prefix + ".up.0.bias")
+    if spec.use_mbconv:             # MBUpConvBlock (mbconv.py:201-250): conv1 -> conv2 (norm 'batch'), no outer residual
+        o1 = mbconv_layer(ctx, [up, sk], prefix + ".conv1", 1, "batch", spec, None)
+        return mbconv_layer(ctx, [o1], prefix + ".conv2", 1, "batch", spec, None)
     o1 = conv_layer(ctx, [up, sk], prefix + ".conv1", 1, "batch", 3, 1, 1, spec, None)
     return conv_layer(ctx, [o1], prefix + ".conv2", 1, "batch", 3, 1, 1, spec, None, residual=o1)
 
@@ -162,6 +208,10 @@ def _decoder_and_head(ctx, out, skips, spec, att):
     keep_maps = maps if (spec.return_maps or spec.encoder) else None
     if spec.encoder:
         return BackboneOutput(None, att, None, keep_maps, out)
+    if spec.use_mbconv:             # MBConvBlock heads: their norm defaults to 'group' (mbconv.py:136-141)
+        logits = mbconv_layer(ctx, [out], "out_conv.conv", len(spec.out_conv), "group", spec, None)
+        boundary = mbconv_layer(ctx, [out], "boundary_conv.conv", 2, "group", spec, None) if spec.add_boundary_loss else None
+        return BackboneOutput(logits, att, boundary, keep_maps, out)
     logits = conv_layer(ctx, [out], "out_conv.conv", len(spec.out_conv), "batch", 3, 1, 1, spec, None)
     boundary = None
     if spec.add_boundary_loss:

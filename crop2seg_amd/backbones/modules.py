@@ -128,6 +128,87 @@ class UpConvBlock(_Holder):
         self.conv2 = ConvLayer([d_out, d_out], norm=norm, padding_mode=padding_mode, conv_type=conv_type)
 
 
+class ResidualAdd(_Holder):
+    """reference mbconv.py:10-22."""
+
+    def __init__(self, block: nn.Module):
+        super().__init__()
+        self.block = block
+
+
+def _norm_layer(norm, n_groups=4):
+    if norm == "batch":
+        return nn.BatchNorm2d
+    if norm == "instance":
+        return nn.InstanceNorm2d
+    if norm == "group":
+        return lambda c: nn.GroupNorm(num_channels=c, num_groups=n_groups)     # raises for c % n_groups != 0, as the reference does
+    raise NotImplementedError(f"norm={norm!r}: crop2seg_amd builds 'group', 'batch' and 'instance'")
+
+
+class MBConv(nn.Sequential):
+    """reference mbconv.py:25-97: Sequential(Sequential(residual(Sequential(1x1 expansion, norm, ReLU, depthwise 3x3 reflect,
+    norm, ReLU, SqueezeAndExcitation, 1x1 projection, norm)))) with residual = ResidualAdd when in == out channels."""
+
+    def __init__(self, in_channels: int, out_channels: int, expansion: int = 4, n_groups: int = 4, add_squeeze: bool = True,
+                 norm: str = "group"):
+        if expansion != 4 or n_groups != 4 or not add_squeeze:
+            raise NotImplementedError("MBConv: expansion 4, 4 normalisation groups and squeeze-and-excitation are built")
+        nl = _norm_layer(norm, n_groups)
+        e = in_channels * expansion
+        inner = nn.Sequential(nn.Conv2d(in_channels, e, kernel_size=1), nl(e), nn.ReLU(),
+                              nn.Conv2d(e, e, groups=e, kernel_size=3, padding=1, padding_mode="reflect"), nl(e), nn.ReLU(),
+                              SqueezeAndExcitation(e, reduction_ratio=16),
+                              nn.Conv2d(e, out_channels, kernel_size=1), nl(out_channels))
+        residual = ResidualAdd if in_channels == out_channels else nn.Sequential
+        super().__init__(nn.Sequential(residual(inner)))
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("MBConv is a parameter holder; run the enclosing backbone instead")
+
+
+class MBConvLayer(_Holder):
+    """reference mbconv.py:100-128."""
+
+    def __init__(self, nkernels, norm):
+        super().__init__()
+        self.conv = nn.Sequential(*[MBConv(nkernels[i], nkernels[i + 1], expansion=4, norm=norm) for i in range(len(nkernels) - 1)])
+
+
+class MBConvBlock(_Holder):
+    """reference mbconv.py:131-152 (padding_mode / conv_type / add_squeeze are swallowed by **kwargs there, too)."""
+
+    def __init__(self, nkernels, pad_value=None, norm="group", *args, **kwargs):
+        super().__init__()
+        self.pad_value = pad_value
+        self.conv = MBConvLayer(nkernels=nkernels, norm=norm)
+
+
+class MBDownConvBlock(_Holder):
+    """reference mbconv.py:155-198: a classical ConvLayer for the strided down-sampling, then two MBConvLayers."""
+
+    def __init__(self, d_in, d_out, k, s, p, pad_value=None, norm="batch", padding_mode="reflect", conv_type="2d", *args,
+                 **kwargs):
+        super().__init__()
+        self.pad_value = pad_value
+        self.down = ConvLayer([d_in, d_in], norm=norm, k=k, s=s, p=p, padding_mode=padding_mode, conv_type=conv_type)
+        self.conv1 = MBConvLayer([d_in, d_out], norm=norm)
+        self.conv2 = MBConvLayer([d_out, d_out], norm=norm)
+
+
+class MBUpConvBlock(_Holder):
+    """reference mbconv.py:201-250."""
+
+    def __init__(self, d_in, d_out, k, s, p, d_skip=None, norm="batch", *args, **kwargs):
+        super().__init__()
+        d = d_out if d_skip is None else d_skip
+        self.skip_conv = nn.Sequential(nn.Conv2d(d, d, kernel_size=1), nn.BatchNorm2d(d), nn.ReLU())
+        self.up = nn.Sequential(nn.ConvTranspose2d(d_in, d_out, kernel_size=k, stride=s, padding=p),
+                                nn.BatchNorm2d(d_out), nn.ReLU())
+        self.conv1 = MBConvLayer([d_out + d, d_out], norm=norm)
+        self.conv2 = MBConvLayer([d_out, d_out], norm=norm)
+
+
 class LightweightMultiHeadAttention(_Holder):
     """reference tae.py:738-758: learnable master query Q [n_head, n, d_k] and the key projection fc1_k."""
 
@@ -354,13 +435,12 @@ class _Backbone(nn.Module):
 def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_conv, str_conv_k, str_conv_s, str_conv_p,
                  agg_mode, encoder_norm, n_head, d_model, d_k, encoder, return_maps, pad_value, padding_mode, conv_type,
                  use_mbconv, add_squeeze_excit, use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss):
-    unsupported = dict(use_mbconv=use_mbconv)
-    bad = [k for k, v in unsupported.items() if v]
-    if bad or conv_type not in ("2d", "depthwise_separable") or agg_mode not in ("att_group", "att_mean", "mean"):
+    bad = []
+    if conv_type not in ("2d", "depthwise_separable") or agg_mode not in ("att_group", "att_mean", "mean"):
         raise NotImplementedError(
             "crop2seg_amd builds the reference's default blocks (train.py:32-47,153-166) plus agg_mode in {att_group, att_mean, "
             "mean}, conv_type in {2d, depthwise_separable}, encoder_norm in {group, batch, instance}, add_boundary_loss, encoder, "
-            "return_maps, add_squeeze_excit and the positional encoders of use_doy / use_abs_rel_enc / add_linear; not built: "
+            "return_maps, add_squeeze_excit, use_mbconv and the positional encoders of use_doy / use_abs_rel_enc / add_linear; not built: "
             f"{bad or dict(conv_type=conv_type, agg_mode=agg_mode)}")
     if encoder:
         return_maps = True                      # utae.py:129-130
@@ -384,24 +464,27 @@ def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_con
                                 pad_value=float(pad_value), padding_mode=padding_mode, conv_type=conv_type,
                                 add_boundary_loss=bool(add_boundary_loss), encoder=bool(encoder),
                                 return_maps=bool(return_maps), pe_mode=_pe_mode(use_abs_rel_enc, use_doy, add_linear),
-                                num_queries=int(num_queries), add_squeeze_excit=bool(add_squeeze_excit))
-    self.add_squeeze_excit = bool(add_squeeze_excit)
+                                num_queries=int(num_queries), add_squeeze_excit=bool(add_squeeze_excit) and not use_mbconv,
+                                use_mbconv=bool(use_mbconv))
+    self.add_squeeze_excit, self.use_mbconv = bool(add_squeeze_excit), bool(use_mbconv)
     self.use_abs_rel_enc, self.use_doy, self.add_linear, self.num_queries = use_abs_rel_enc, use_doy, add_linear, num_queries
     self.add_boundary_loss = bool(add_boundary_loss)
     return decoder_widths
 
 
-def _enc_blocks(encoder_widths, k, s, p, pad_value, norm, padding_mode, conv_type="2d", add_squeeze=False):
+def _enc_blocks(encoder_widths, k, s, p, pad_value, norm, padding_mode, conv_type="2d", add_squeeze=False, use_mbconv=False):
+    block = MBDownConvBlock if use_mbconv else DownConvBlock            # utae.py:118-122
     return nn.ModuleList(
-        DownConvBlock(d_in=encoder_widths[i], d_out=encoder_widths[i + 1], k=k, s=s, p=p, pad_value=pad_value,
+        block(d_in=encoder_widths[i], d_out=encoder_widths[i + 1], k=k, s=s, p=p, pad_value=pad_value,
                       norm=norm, padding_mode=padding_mode, conv_type=conv_type, add_squeeze=add_squeeze)
         for i in range(len(encoder_widths) - 1))
 
 
-def _dec_blocks(encoder_widths, decoder_widths, k, s, p, padding_mode):
+def _dec_blocks(encoder_widths, decoder_widths, k, s, p, padding_mode, use_mbconv=False):
     n = len(encoder_widths)
+    block = MBUpConvBlock if use_mbconv else UpConvBlock
     return nn.ModuleList(
-        UpConvBlock(d_in=decoder_widths[i], d_out=decoder_widths[i - 1], d_skip=encoder_widths[i - 1], k=k, s=s, p=p,
+        block(d_in=decoder_widths[i], d_out=decoder_widths[i - 1], d_skip=encoder_widths[i - 1], k=k, s=s, p=p,
                     norm="batch", padding_mode=padding_mode)
         for i in range(n - 1, 0, -1))
 
@@ -419,17 +502,20 @@ class UTAE(_Backbone):
                                       str_conv_s, str_conv_p, agg_mode, encoder_norm, n_head, d_model, d_k, encoder,
                                       return_maps, pad_value, padding_mode, conv_type, use_mbconv, add_squeeze_excit,
                                       use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss)
-        self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
+        conv_block, head_block = (MBConvBlock, MBConvBlock) if use_mbconv else (ConvBlock, ConvBlock)      # utae.py:118-126
+        self.in_conv = conv_block([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
                                  norm=encoder_norm, padding_mode=padding_mode, conv_type=conv_type,
                                  add_squeeze=bool(add_squeeze_excit))
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
-                                       padding_mode, conv_type=conv_type, add_squeeze=bool(add_squeeze_excit))
-        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
+                                       padding_mode, conv_type=conv_type, add_squeeze=bool(add_squeeze_excit),
+                                       use_mbconv=bool(use_mbconv))
+        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode,
+                                     use_mbconv=bool(use_mbconv))
         self.temporal_encoder = LTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k, use_abs_rel_enc=use_abs_rel_enc, num_queries=num_queries, use_doy=use_doy, add_linear=add_linear)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
-        self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
+        self.out_conv = head_block([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
         if add_boundary_loss:                                           # utae.py:195-198
-            self.boundary_conv = ConvBlock([decoder_widths[0]] + [32, 2], padding_mode=padding_mode)
+            self.boundary_conv = head_block([decoder_widths[0]] + [32, 2], padding_mode=padding_mode)
 
 
 class TimeUNet_v1(_Backbone):
@@ -471,16 +557,20 @@ class WTAE(_Backbone):
                                       str_conv_s, str_conv_p, agg_mode, encoder_norm, n_head, d_model, d_k, encoder,
                                       return_maps, pad_value, padding_mode, conv_type, use_mbconv, add_squeeze_excit,
                                       use_abs_rel_enc, num_queries, use_doy, add_linear, add_boundary_loss)
-        self.in_conv = ConvBlock([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
+        conv_block, head_block = (MBConvBlock, MBConvBlock) if use_mbconv else (ConvBlock, ConvBlock)      # utae.py:118-126
+        self.in_conv = conv_block([input_dim, encoder_widths[0], encoder_widths[0]], pad_value=pad_value,
                                  norm=encoder_norm, padding_mode=padding_mode, conv_type=conv_type,
                                  add_squeeze=bool(add_squeeze_excit))
         self.spatial_reduction = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
-                                             padding_mode, conv_type="depthwise_separable", add_squeeze=bool(add_squeeze_excit))
+                                             padding_mode, conv_type="depthwise_separable", add_squeeze=bool(add_squeeze_excit),
+                                             use_mbconv=bool(use_mbconv))
         self.down_blocks = _enc_blocks(encoder_widths, str_conv_k, str_conv_s, str_conv_p, pad_value, encoder_norm,
-                                       padding_mode, conv_type=conv_type, add_squeeze=bool(add_squeeze_excit))
-        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode)
+                                       padding_mode, conv_type=conv_type, add_squeeze=bool(add_squeeze_excit),
+                                       use_mbconv=bool(use_mbconv))
+        self.up_blocks = _dec_blocks(encoder_widths, decoder_widths, str_conv_k, str_conv_s, str_conv_p, padding_mode,
+                                     use_mbconv=bool(use_mbconv))
         self.temporal_encoder = LTAE4WTAE(in_channels=encoder_widths[-1], d_model=d_model, n_head=n_head, d_k=d_k, use_abs_rel_enc=use_abs_rel_enc, num_queries=num_queries, use_doy=use_doy, add_linear=add_linear)
         self.temporal_aggregator = TemporalAggregator(mode=agg_mode)
-        self.out_conv = ConvBlock([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
+        self.out_conv = head_block([decoder_widths[0]] + list(out_conv), padding_mode=padding_mode)
         if add_boundary_loss:                                           # wtae.py:215-218
-            self.boundary_conv = ConvBlock([decoder_widths[0]] + [32, 2], padding_mode=padding_mode)
+            self.boundary_conv = head_block([decoder_widths[0]] + [32, 2], padding_mode=padding_mode)

@@ -166,7 +166,28 @@ __global__ __launch_bounds__(256) void se_param_reduce_kernel(const float* __res
     else gW2[e - RC] = acc2 ? gW2[e - RC] + (float)s : (float)s;
 }
 
+// x[n,c,:] += bias[c] on the frames that are real (the depthwise convolution of MBConv has a bias, mbconv.py:71-79; the
+// depthwise kernels of misc.hip serve DepthwiseSeparableConv2D, which has none)
+__global__ __launch_bounds__(256) void channel_bias_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                           const int* __restrict__ valid, int C, int HW, long total) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / HW;
+        if (valid != nullptr && valid[row / C] == 0) continue;
+        x[e] += bias[row % C];
+    }
+}
+
 }  // namespace
+
+extern "C" int c2s_channel_bias_add(float* x, const float* bias, const int* valid, int N, int C, int HW, void* stream) {
+    C2S_REQUIRE(x && bias && N > 0 && C > 0 && HW > 0, "channel_bias_add: bad args");
+    const long total = (long)N * C * HW;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(channel_bias_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, x,
+                       bias, valid, C, HW, total);
+    C2S_CHECK_LAUNCH("channel_bias_add");
+    return C2S_OK;
+}
 
 // workspace: part [rows*segs] | pw [N * 2*R*C] | dpool [N*C]
 extern "C" size_t c2s_se_workspace_floats(int N, int C, int HW) {

@@ -531,8 +531,9 @@ def conv_transpose2d(ctx: Ctx, x: Tensor, wname: str, bname: str) -> Tensor:
 
 
 def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, pad_mode: int,
-                     valid: Optional[Tensor]) -> Tensor:
-    """Depthwise part of DepthwiseSeparableConv2D (reference conv.py:18-20)."""
+                     valid: Optional[Tensor], bname: Optional[str] = None) -> Tensor:
+    """Depthwise part of DepthwiseSeparableConv2D (reference conv.py:18-20; bias-free) and the depthwise convolution of
+    MBConv (mbconv.py:71-79; `bname`: its bias, whose gradient the following norm_act(conv_bias=bname) delivers)."""
     W = ctx.p[wname]
     N, Cc, Hin, Win = x.shape
     Ho = (Hin + 2 * pad - K) // S + 1
@@ -540,6 +541,9 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
     out = torch.empty(N, Cc, Ho, Wo, device=x.device, dtype=torch.float32)
     check(lib().c2s_dwconv_fwd(x.data_ptr(), W.data_ptr(), out.data_ptr(), _ptr(valid), N, Cc, Hin, Win, K, S, pad,
                                pad_mode, _stream()), "dwconv_fwd")
+    if bname is not None:
+        check(lib().c2s_channel_bias_add(out.data_ptr(), ctx.p[bname].data_ptr(), _ptr(valid), N, Cc, Ho * Wo, _stream()),
+              "channel_bias_add")
     if ctx.tape is None:
         return out
     tape = ctx.tape

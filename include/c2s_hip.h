@@ -256,6 +256,9 @@ int c2s_norm_bwd_onepass(const c2s_norm_desc* d, const float* x, const float* g,
  * filled with pad_value.  c2s_se_bwd: gx (may alias g), gW1 / gW2 (acc_* != 0: accumulate).  16 <= C <= 1024.
  * ------------------------------------------------------------------------------------------------ */
 size_t c2s_se_workspace_floats(int N, int C, int HW);
+/* x[n,c,:] += bias[c] on real frames: the bias of MBConv's depthwise convolution (mbconv.py:71-79), applied after
+ * c2s_dwconv_fwd; its gradient is the per-channel sum of dx that c2s_norm_bwd_params delivers as dbias. */
+int c2s_channel_bias_add(float* x, const float* bias, const int* valid, int N, int C, int HW, void* stream);
 int c2s_se_fwd(const float* x, const float* W1, const float* W2, float* pooled, float* hidden, float* scale, float* y,
                const int* valid, int N, int C, int HW, float pad_value, float* workspace, size_t ws_floats, void* stream);
 int c2s_se_bwd(const float* x, const float* g, const float* W1, const float* W2, const float* pooled, const float* hidden,

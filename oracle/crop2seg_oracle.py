@@ -71,6 +71,7 @@ class BackboneConfig:
     use_abs_rel_enc: bool = False
     add_linear: bool = False
     add_squeeze_excit: bool = False          # SqueezeAndExcitation after in_conv and the encoder down blocks (utae.py:145,159)
+    use_mbconv: bool = False                 # MBConv blocks instead of the classical conv blocks (utae.py:118-122; mbconv.py)
     attn_dropout: float = 0.1                # tae.py:816
     mlp_dropout: float = 0.2                 # tae.py:361
     bn_momentum: float = 0.1
@@ -187,6 +188,41 @@ def conv_layer(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, k: in
     return x
 
 
+def _norm(x: Tensor, sd: State, prefix: str, norm: str, cfg: BackboneConfig, training: bool, bn: Optional[BNState]) -> Tensor:
+    if norm == "group":
+        return F.group_norm(x, 4, sd[prefix + ".weight"], sd[prefix + ".bias"], cfg.eps)
+    if norm == "batch":
+        return batch_norm(x, sd, prefix, training, cfg, bn)
+    if norm == "instance":
+        return F.instance_norm(x, eps=cfg.eps)
+    raise ValueError(norm)
+
+
+def mbconv(x: Tensor, sd: State, prefix: str, norm: str, cfg: BackboneConfig, training: bool, bn: Optional[BNState]) -> Tensor:
+    """MBConv (mbconv.py:25-97): 1x1 expansion (x4) -> norm -> ReLU -> depthwise 3x3 (reflect, WITH bias) -> norm -> ReLU ->
+    SqueezeAndExcitation -> 1x1 projection -> norm, wrapped in ResidualAdd when in == out channels.  `prefix` names the MBConv
+    (a Sequential in a Sequential): the inner block is prefix.0.0.block.* with the residual, prefix.0.0.0.* without."""
+    res = (prefix + ".0.0.block.0.weight") in sd
+    base = prefix + (".0.0.block" if res else ".0.0.0")
+    o = F.conv2d(x, sd[base + ".0.weight"], sd[base + ".0.bias"])
+    o = relu(_norm(o, sd, base + ".1", norm, cfg, training, bn))
+    dw = sd[base + ".3.weight"]
+    o = conv2d(o, dw, sd[base + ".3.bias"], 1, 1, "reflect", groups=dw.shape[0])
+    o = relu(_norm(o, sd, base + ".4", norm, cfg, training, bn))
+    o = squeeze_excite(o, sd, base + ".6")
+    o = F.conv2d(o, sd[base + ".7.weight"], sd[base + ".7.bias"])
+    o = _norm(o, sd, base + ".8", norm, cfg, training, bn)
+    return o + x if res else o
+
+
+def mbconv_layer(x: Tensor, sd: State, prefix: str, n: int, norm: str, cfg: BackboneConfig, training: bool,
+                 bn: Optional[BNState]) -> Tensor:
+    """MBConvLayer (mbconv.py:100-128): n MBConv blocks, prefix.conv.{i}."""
+    for i in range(n):
+        x = mbconv(x, sd, f"{prefix}.conv.{i}", norm, cfg, training, bn)
+    return x
+
+
 def frame_pad_mask(x5: Tensor, pad_value: float) -> Tensor:
     """[B,T] mask of frames equal to pad_value everywhere (utae.py:201-203)."""
     return (x5 == pad_value).flatten(2).all(dim=-1)
@@ -218,7 +254,9 @@ def shared_over_time(fn, x: Tensor, pad_value: Optional[float]) -> Tensor:
 def conv_block(x: Tensor, sd: State, prefix: str, n_convs: int, norm: str, cfg: BackboneConfig,
                training: bool, bn: Optional[BNState], pad_value: Optional[float], depthwise_separable: bool = False,
                add_squeeze: bool = False) -> Tensor:
-    """ConvBlock (conv.py:168-200) applied through smart_forward."""
+    """ConvBlock (conv.py:168-200) applied through smart_forward; with use_mbconv: MBConvBlock (mbconv.py:131-152)."""
+    if cfg.use_mbconv:
+        return shared_over_time(lambda z: mbconv_layer(z, sd, prefix + ".conv", n_convs, norm, cfg, training, bn), x, pad_value)
     return shared_over_time(
         lambda z: conv_layer(z, sd, prefix + ".conv", n_convs, norm, 3, 1, 1, cfg, training, bn, depthwise_separable,
                              add_squeeze),
@@ -232,6 +270,9 @@ def down_conv_block(x: Tensor, sd: State, prefix: str, norm: str, cfg: BackboneC
     def fn(z: Tensor) -> Tensor:
         o = conv_layer(z, sd, prefix + ".down", 1, norm, cfg.str_conv_k, cfg.str_conv_s, cfg.str_conv_p,
                        cfg, training, bn, depthwise_separable)
+        if cfg.use_mbconv:               # MBDownConvBlock (mbconv.py:155-198): down -> conv1 -> conv2, no outer residual
+            o = mbconv_layer(o, sd, prefix + ".conv1", 1, norm, cfg, training, bn)
+            return mbconv_layer(o, sd, prefix + ".conv2", 1, norm, cfg, training, bn)
         o = conv_layer(o, sd, prefix + ".conv1", 1, norm, 3, 1, 1, cfg, training, bn, depthwise_separable)
         o = o + conv_layer(o, sd, prefix + ".conv2", 1, norm, 3, 1, 1, cfg, training, bn, depthwise_separable)
         return squeeze_excite(o, sd, prefix + ".sae") if add_squeeze else o
@@ -248,6 +289,9 @@ def up_conv_block(x: Tensor, skip: Tensor, sd: State, prefix: str, cfg: Backbone
                             stride=cfg.str_conv_s, padding=cfg.str_conv_p)
     up = relu(batch_norm(up, sd, prefix + ".up.1", training, cfg, bn))
     o = torch.cat([up, sk], dim=1)
+    if cfg.use_mbconv:                   # MBUpConvBlock (mbconv.py:201-250): conv1 -> conv2 (MBConvLayers, norm 'batch'), no outer residual
+        o = mbconv_layer(o, sd, prefix + ".conv1", 1, "batch", cfg, training, bn)
+        return mbconv_layer(o, sd, prefix + ".conv2", 1, "batch", cfg, training, bn)
     o = conv_layer(o, sd, prefix + ".conv1", 1, "batch", 3, 1, 1, cfg, training, bn)
     return o + conv_layer(o, sd, prefix + ".conv2", 1, "batch", 3, 1, 1, cfg, training, bn)
 
@@ -389,6 +433,12 @@ def _decoder_and_head(out: Tensor, skips: List[Tensor], sd: State, cfg: Backbone
     for i in range(n_stages - 1):
         out = up_conv_block(out, skips[i], sd, f"up_blocks.{i}", cfg, training, bn)
     # out_conv = ConvBlock([dec0]+out_conv), BatchNorm + ReLU after BOTH convs (utae.py:191; conv.py:184)
+    if cfg.use_mbconv:                   # out_conv = MBConvBlock(nkernels): its norm defaults to 'group' (mbconv.py:136-141)
+        logits = mbconv_layer(out, sd, "out_conv.conv", len(cfg.out_conv), "group", cfg, training, bn)
+        if cfg.add_boundary_loss:
+            LAST_BOUNDARY.clear()
+            LAST_BOUNDARY.append(mbconv_layer(out, sd, "boundary_conv.conv", 2, "group", cfg, training, bn))
+        return logits
     logits = conv_layer(out, sd, "out_conv.conv", len(cfg.out_conv), "batch", 3, 1, 1, cfg, training, bn)
     if cfg.add_boundary_loss:                # utae.py:236-238: out_ = out_conv(out); out_b = boundary_conv(out)
         LAST_BOUNDARY.clear()

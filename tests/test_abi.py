@@ -92,8 +92,10 @@ def test_no_cpu_fallback():
 
 def test_offdefault_flags_fail_loudly():
     import crop2seg_amd as C2S
-    with pytest.raises(NotImplementedError):
-        C2S.UTAE(input_dim=10, use_mbconv=True)
+    with pytest.raises(ValueError, match="divisible"):          # the reference's constructor raises the same way: the GroupNorm(4)
+        C2S.UTAE(input_dim=10, out_conv=[32, 15], use_mbconv=True)     # head of MBConvBlock needs a multiple of 4 classes
+    assert len(C2S.UTAE(input_dim=10, out_conv=[32, 20], use_mbconv=True).state_dict()) == 348
+    assert len(C2S.WTAE(input_dim=10, out_conv=[32, 20], use_mbconv=True).state_dict()) == 435
     with pytest.raises(NotImplementedError):
         C2S.WTAE(input_dim=10, agg_mode="max")
     with pytest.raises(NotImplementedError):

@@ -29,7 +29,7 @@ def test_oracle_matches_reference_forward(goldens, name):
         if g.cfg.model == "wtae":
             kw.pop("mlp_keep", None)
         logits, att = O.forward(g.sd, g.x, g.dates, g.cfg, training=g.training, bn=bn, **kw)
-        loss = O.cross_entropy(logits, g.y, 15)
+        loss = O.cross_entropy(logits, g.y, g.cfg.out_conv[-1])
         if g.cfg.add_boundary_loss:          # second head + focal term (utae.py:236-238; src/learning/utils.py:283-285,318-324)
             from oracle import tail_oracle as TO
             out_b = O.LAST_BOUNDARY[0]
@@ -64,6 +64,8 @@ def test_oracle_matches_reference_backward(goldens, name):
         kw.pop("mlp_keep", None)
     _, loss, grads, _ = O.loss_and_grads(g.sd, g.x, g.dates, g.y, g.cfg, g.training, **kw)
     names = g.grad_names()
+    if not names:
+        pytest.skip("forward-only fixture (oracle/make_golden.py says why)")
     assert set(names) == set(grads.keys())
     gmax = max(float(g.z[f"grad/{n}/norm"]) for n in names)
     # eval mode: tight against the reference's gradients.  train mode: fp64-anchored criterion (Golden.fp64_anchor).
