@@ -73,6 +73,7 @@ SIGNATURES = {
     "c2s_bf16x3_packed_elems": (SZ, [I, I]),
     "c2s_pack_weights_bf16x3": (I, [P, P, P, I, I, I, I, L, L, C.POINTER(I), P]),
     "c2s_conv3x3_bf16x3": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "c2s_bf16x3_set_single_product": (None, [I]),
     "c2s_wgrad_workspace_floats": (SZ, [C.POINTER(WgradDesc)]),
     "c2s_conv_wgrad": (I, [C.POINTER(WgradDesc), P, P, P, P, SZ, P, P]),
     "c2s_wgrad_reduce": (I, [C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, P]),

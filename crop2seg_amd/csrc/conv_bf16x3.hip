@@ -35,16 +35,17 @@ struct BxParams {
     int pad_mode, accumulate;
     int log2fc, tiles_x;
     int adj, ay_lo, ay_hi, ax_lo, ax_hi;
+    int single;            // measurement mode: activations rounded to bf16 (no lo part) -- with zeroed wlo a plain bf16 x bf16 product
 };
 
 constexpr int BX_CK = 8, BX_NTP = 10, BX_NSTEP = 5;
 
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo, bool single) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const __bf16 h = (__bf16)x[j];
         hi[j] = h;
-        lo[j] = (__bf16)(x[j] - (float)h);
+        lo[j] = single ? (__bf16)0.f : (__bf16)(x[j] - (float)h);
     }
 }
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16x3_kernel(BxParams p) {
             const int e = tid + i * 256;
             if (e < plane) {
                 bf16x8 hi, lo;
-                split8(xr[i], hi, lo);
+                split8(xr[i], hi, lo, p.single != 0);
                 *reinterpret_cast<bf16x8*>(Xh + e * 8) = hi;
                 *reinterpret_cast<bf16x8*>(Xl + e * 8) = lo;
             }
@@ -340,7 +341,7 @@ struct TapTable {
 
 // whi/wlo[chunk][tap (NTP)][coutP][8 cin] <- split of src[o*so + c*sc + tap_off[t]]
 __global__ void pack_bf16x3_kernel(const float* __restrict__ src, __bf16* __restrict__ whi, __bf16* __restrict__ wlo, int cin,
-                                   int cout, int coutP, int ntaps, long so, long sc, TapTable tt) {
+                                   int cout, int coutP, int ntaps, long so, long sc, TapTable tt, int single) {
     const int nchunks = (cin + BX_CK - 1) / BX_CK;
     const long total = (long)nchunks * BX_NTP * coutP * 8;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -354,7 +355,7 @@ __global__ void pack_bf16x3_kernel(const float* __restrict__ src, __bf16* __rest
         if (o < cout && t < ntaps && c < cin) v = src[o * so + c * sc + tt.off[t]];
         const __bf16 h = (__bf16)v;
         whi[e] = h;
-        wlo[e] = (__bf16)(v - (float)h);
+        wlo[e] = single ? (__bf16)0.f : (__bf16)(v - (float)h);
     }
 }
 
@@ -375,6 +376,12 @@ extern "C" size_t c2s_bf16x3_packed_elems(int cin, int coutP) {
     return (size_t)((cin + BX_CK - 1) / BX_CK) * BX_NTP * coutP * 8;
 }
 
+// Measurement switch ("report the bf16 deviation from the fp32 oracle"): != 0 drops the lo parts of weights and
+// activations, i.e. the 3x3 stride-1 convolutions run as plain bf16 x bf16 products with fp32 accumulation.  Process-wide,
+// read by the pack and convolution launchers; never set on the product path.
+static int g_single_product = 0;
+extern "C" void c2s_bf16x3_set_single_product(int on) { g_single_product = on != 0; }
+
 extern "C" int c2s_pack_weights_bf16x3(const float* src, void* whi, void* wlo, int cin, int cout, int coutP, int ntaps,
                                        long stride_o, long stride_c, const int* host_tap_off, void* stream) {
     C2S_REQUIRE(src && whi && wlo && host_tap_off, "pack_bf16x3: null pointer");
@@ -384,7 +391,7 @@ extern "C" int c2s_pack_weights_bf16x3(const float* src, void* whi, void* wlo, i
     const long total = (long)c2s_bf16x3_packed_elems(cin, coutP);
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)whi, (__bf16*)wlo,
-                       cin, cout, coutP, ntaps, stride_o, stride_c, tt);
+                       cin, cout, coutP, ntaps, stride_o, stride_c, tt, g_single_product);
     C2S_CHECK_LAUNCH("pack_bf16x3");
     return C2S_OK;
 }
@@ -404,6 +411,7 @@ extern "C" int c2s_conv3x3_bf16x3(const c2s_conv_desc* d, const float* src0, con
     p.valid = valid; p.C0 = d->C0; p.C1 = d->C1; p.Hin = d->Hin; p.Win = d->Win; p.Cout = d->Cout; p.CoutP = d->CoutP;
     p.Hout = d->Hout; p.Wout = d->Wout; p.pad_mode = d->pad_mode; p.accumulate = d->accumulate;
     p.adj = d->reflect_adjoint;
+    p.single = g_single_product;
     p.ay_lo = p.ay_hi = p.ax_lo = p.ax_hi = -1;
     if (d->reflect_adjoint) {
         C2S_REQUIRE(d->pad_mode == C2S_PAD_ZEROS && d->Hin != 3 && d->Win != 3, "conv3x3_bf16x3: bad adjoint geometry");

@@ -154,6 +154,9 @@ int c2s_pack_weights_bf16x3(const float* src, void* whi, void* wlo, int cin, int
                             long stride_o, long stride_c, const int* host_tap_off, void* stream);
 int c2s_conv3x3_bf16x3(const c2s_conv_desc* d, const float* src0, const float* src1, const void* whi,
                        const void* wlo, const float* bias, float* out, const int* valid, void* stream);
+/* Measurement switch: != 0 drops the lo parts (plain bf16 x bf16 products, fp32 accumulation) in the two calls above, to report
+ * the deviation of bf16 inputs from the fp32 path (tools/bf16_deviation.py).  Process-wide; off by default. */
+void c2s_bf16x3_set_single_product(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient (convolution_backward-weight of the same call sites), split-K over output tiles:
