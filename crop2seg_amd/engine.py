@@ -31,7 +31,7 @@ import os as _os
 _SIDE = None
 SIDE_WGRAD = _os.environ.get("C2S_WGRAD_STREAM", "1") != "0"
 SIDE_BATCH = int(_os.environ.get("C2S_WGRAD_BATCH", "8"))
-SIDE_FLUSH_POSITIONS = int(_os.environ.get("C2S_WGRAD_FLUSH_POSITIONS", str(1 << 19)))
+SIDE_FLUSH_POSITIONS = int(_os.environ.get("C2S_WGRAD_FLUSH_POSITIONS", str(1 << 22)))
 # While a hipGraph is being captured the fork / join events become cross-stream edges of the graph.  Measured (round 3,
 # U-TAE B=4 T=32): the captured two-stream step replays at 17.1 ms against 12.65 ms for the single-stream capture and
 # 12.25 ms for eager two-stream launches -- the graph executor serialises around the cross-stream edges -- so a capture stays
@@ -385,8 +385,9 @@ def _wgrad(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hout: int,
         ctx.tape.defer(lambda: _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps,
                                              accumulate, valid), [gout, *srcs])
         if srcs[0].shape[0] * Hout * Wout >= SIDE_FLUSH_POSITIONS:
-            ctx.tape.flush_side()       # the full-resolution layers come last in the backward pass: start them now, while
-                                        # the rest of the chain can still overlap them, instead of after it
+            ctx.tape.flush_side()       # very large layers (TimeUNet's 8M-position planes) come last in the backward pass: start
+                                        # them now instead of after the rest of the batch.  (Round 3: with the one-pass norm
+                                        # kernels the U-TAE layers of 2M positions run 0.15 ms/step better batched: 1<<22.)
     else:
         _wgrad_launch(ctx, srcs, gout, Cout, Hout, Wout, K, S, pad, pad_mode, dst, so, sc, taps, accumulate, valid)
 
@@ -585,9 +586,10 @@ def depthwise_conv2d(ctx: Ctx, x: Tensor, wname: str, K: int, S: int, pad: int, 
 # group meeting through memory.  C2S_NORM_ONEPASS=0 keeps the two-pass kernels (A/B runs, and the shapes the one-pass
 # form does not take fall back to them anyway).
 ONEPASS_NORM = _os.environ.get("C2S_NORM_ONEPASS", "1") != "0"
-# Below full 2048-float segments a wave holds too little data for the meeting to pay (tools/norm_bench.py: 32x32 planes break
-# even, 16x16 planes lose 30-140 %): those layers keep the two-pass kernels.
-ONEPASS_MIN_HW = int(_os.environ.get("C2S_NORM_ONEPASS_MIN_HW", "2048"))
+# Small planes: a wave holds too little data for the meeting to pay (tools/norm_bench.py, isolated: 32x32 planes break even,
+# 16x16 planes lose 30-140 %).  Inside a step 32x32 planes still win (one launch instead of two per direction: U-TAE 12.26 ->
+# 12.11 ms over three A/B runs), 16x16 planes do not (12.10 vs 12.04): planes below 1024 pixels keep the two-pass kernels.
+ONEPASS_MIN_HW = int(_os.environ.get("C2S_NORM_ONEPASS_MIN_HW", "1024"))
 
 
 def norm_act(ctx: Ctx, x: Tensor, prefix: str, kind: int, groups: int, relu: bool, residual: Optional[Tensor],
