@@ -27,6 +27,7 @@ struct CollateParams {
     float mean[16], stdv[16];   // in OUTPUT channel order (reference norm_values, already re-ordered)
     int normalise;
     float pad_value;
+    int ndvi_a, ndvi_b;         // >= 0: the LAST output channel is the NDVI of source channels (a, b), not normalised
 };
 
 template <typename S> struct Vec4;
@@ -53,6 +54,27 @@ __global__ __launch_bounds__(256) void collate_kernel(CollateParams p) {
         return;
     }
     using V = typename Vec4<S>::type;
+    if (p.ndvi_a >= 0 && c == p.C - 1) {
+        // add_ndvi (s2_ts_cz_crop.py:376-391,401-402): (NIR - red) / (NIR + red) of the raw bands, 0 where the sum is 0 and where
+        // the quotient leaves [-1, 1]; appended after the normalised bands, itself not normalised.  IEEE fp32 add / sub / div.
+        const V* ia = reinterpret_cast<const V*>(static_cast<const S*>(p.src) + ((size_t)(beg + t) * p.Cs + p.ndvi_a) * p.HW);
+        const V* ib = reinterpret_cast<const V*>(static_cast<const S*>(p.src) + ((size_t)(beg + t) * p.Cs + p.ndvi_b) * p.HW);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < q; i += gridDim.x * 256) {
+            const V va = ia[i], vb = ib[i];
+            const float a4[4] = {(float)va.x, (float)va.y, (float)va.z, (float)va.w};
+            const float b4[4] = {(float)vb.x, (float)vb.y, (float)vb.z, (float)vb.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sum = __fadd_rn(a4[k], b4[k]);
+                float v = sum == 0.f ? 0.f : __fdiv_rn(__fsub_rn(a4[k], b4[k]), sum);
+                if (v < -1.f || v > 1.f) v = 0.f;
+                o[k] = v;
+            }
+            out[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     const V* in = reinterpret_cast<const V*>(static_cast<const S*>(p.src) + ((size_t)(beg + t) * p.Cs + p.order[c]) * p.HW);
     const float m = p.mean[c], s = p.stdv[c];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < q; i += gridDim.x * 256) {
@@ -106,15 +128,26 @@ extern "C" int c2s_collate_series(const void* src, int src_dtype, const long lon
                                   float* x, long long* dates, int* valid, int B, int T, int C, int Cs, int HW,
                                   const int* host_channel_order, const float* host_mean, const float* host_std,
                                   float pad_value, void* stream) {
+    return c2s_collate_series_ndvi(src, src_dtype, offsets, src_dates, x, dates, valid, B, T, C, Cs, HW, host_channel_order,
+                                   host_mean, host_std, pad_value, -1, -1, stream);
+}
+
+extern "C" int c2s_collate_series_ndvi(const void* src, int src_dtype, const long long* offsets, const long long* src_dates,
+                                       float* x, long long* dates, int* valid, int B, int T, int C, int Cs, int HW,
+                                       const int* host_channel_order, const float* host_mean, const float* host_std,
+                                       float pad_value, int ndvi_a, int ndvi_b, void* stream) {
     C2S_REQUIRE(src && offsets && x, "collate_series: null pointer");
-    C2S_REQUIRE(B > 0 && T > 0 && C > 0 && C <= 16 && Cs >= C && HW > 0 && HW % 4 == 0, "collate_series: bad shape (C <= 16, HW %% 4 == 0)");
+    const bool ndvi = ndvi_a >= 0 || ndvi_b >= 0;
+    C2S_REQUIRE(!ndvi || (ndvi_a >= 0 && ndvi_a < Cs && ndvi_b >= 0 && ndvi_b < Cs && C >= 2), "collate_series: NDVI source channels out of range");
+    C2S_REQUIRE(B > 0 && T > 0 && C > 0 && C <= 16 && Cs >= C - (ndvi ? 1 : 0) && HW > 0 && HW % 4 == 0, "collate_series: bad shape (C <= 16, HW %% 4 == 0)");
     C2S_REQUIRE((long)B * T < 65536 && C < 65536, "collate_series: too many frames for one launch");
     C2S_REQUIRE((host_mean == nullptr) == (host_std == nullptr), "collate_series: mean and std come together");
     CollateParams p = {};
     p.src = src; p.offsets = offsets; p.src_dates = src_dates; p.x = x; p.dates = dates; p.valid = valid;
     p.B = B; p.T = T; p.C = C; p.Cs = Cs; p.HW = HW; p.pad_value = pad_value;
     p.normalise = host_mean != nullptr;
-    for (int c = 0; c < C; ++c) {
+    p.ndvi_a = ndvi ? ndvi_a : -1; p.ndvi_b = ndvi ? ndvi_b : -1;
+    for (int c = 0; c < C - (ndvi ? 1 : 0); ++c) {
         p.order[c] = host_channel_order ? host_channel_order[c] : c;
         C2S_REQUIRE(p.order[c] >= 0 && p.order[c] < Cs, "collate_series: channel_order entry out of range");
         p.mean[c] = host_mean ? host_mean[c] : 0.f;

@@ -842,7 +842,10 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     p_eff = dropout_p if ctx.training else 0.0
     d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None, _ptr(seed_dev))
     attn = torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
-    attn_pre = torch.empty_like(attn)          # softmax before dropout (backward); score scratch of the streaming kernels
+    # softmax before dropout: saved for the backward (and the score scratch of the three-pass streaming kernels); a forward
+    # without a tape (inference) does not store it: 16*B*T*h*w floats less to write
+    need_pre = ctx.tape is not None or lib().c2s_ltae_fwd_path(C.byref(d)) == 1
+    attn_pre = torch.empty_like(attn) if need_pre else None
     emb = torch.empty(B, d_model, h, w, device=x5.device, dtype=torch.float32) if with_embedding else None
     stats = torch.empty(B * HW * n_head * 2, device=x5.device, dtype=torch.float32)
     Ud, s0d = U, s0

@@ -480,6 +480,13 @@ int c2s_collate_series(const void* src, int src_dtype, const long long* offsets,
                        long long* dates, int* valid, int B, int T, int C, int Cs, int HW,
                        const int* host_channel_order, const float* host_mean, const float* host_std, float pad_value,
                        void* stream);
+/* The same with the dataset's add_ndvi option (s2_ts_cz_crop.py:376-391,401-402): the LAST of the C output channels is
+ * (a - b) / (a + b) of the RAW source channels ndvi_a (NIR) and ndvi_b (red) -- 0 where a + b == 0 or where the quotient leaves
+ * [-1, 1] -- not normalised; channel_order / mean / std then describe the first C - 1 channels.  ndvi_a < 0: no NDVI channel. */
+int c2s_collate_series_ndvi(const void* src, int src_dtype, const long long* offsets, const long long* src_dates, float* x,
+                            long long* dates, int* valid, int B, int T, int C, int Cs, int HW, const int* host_channel_order,
+                            const float* host_mean, const float* host_std, float pad_value, int ndvi_a, int ndvi_b,
+                            void* stream);
 int c2s_softmax_stitch(const float* logits, float* proba, long long* top1, int first_patch, int npatch, int K, int ph,
                        int pw, int grid_w, int out_h, int out_w, void* stream);
 

@@ -1,0 +1,21 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r3_final; mkdir -p $O
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -40 $O/gpu_tests.log; exit 1; }
+tail -3 $O/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail $O/smoke.log; exit 1; }
+tail -1 $O/smoke.log
+python bench.py > $O/bench.json 2> $O/bench.err
+cut -c1-300 $O/bench.json
+python bench.py --model timeunet --batch 8 --T 61 --steps 15 --warmup 3 --no-cpu-baseline > $O/bench_timeunet_b8_t61.json 2> $O/tu.err
+python bench.py --model wtae --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_wtae.json 2> $O/wt.err
+python bench.py --batch 8 --T 48 --size 256 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_utae_b8_t48_256.json 2> $O/c5.err
+python bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_graph.json 2> $O/gr.err
+for f in bench_timeunet_b8_t61 bench_wtae bench_utae_b8_t48_256 bench_graph; do echo "$f $(python -c "import json;print(json.load(open('$O/$f.json'))['ms_per_step'])")"; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_2s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_2s.json 2> $O/prof_2s.err
+C2S_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_1s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_1s.json 2> $O/prof_1s.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tu -- python bench.py --model timeunet --batch 8 --T 61 --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_tu.json 2> $O/prof_tu.err
+timeout -k 10 300 python tools/tile_bench.py > $O/tile_bench.txt 2>&1 || tail -5 $O/tile_bench.txt
+tail -3 $O/tile_bench.txt
+find $O -name '*kernel_trace.csv' -delete
