@@ -129,6 +129,7 @@ SIGNATURES = {
     "c2s_smooth_ce_workspace_floats": (SZ, []),
     "c2s_smooth_ce": (I, [P, P, P, P, P, P, I, I, I, I, F, C.c_longlong, I, P, SZ, P]),
     "c2s_collate_series": (I, [P, I, P, P, P, P, P, I, I, I, I, I, C.POINTER(I), C.POINTER(F), C.POINTER(F), F, P]),
+    "c2s_collate_series_ndvi": (I, [P, I, P, P, P, P, P, I, I, I, I, I, C.POINTER(I), C.POINTER(F), C.POINTER(F), F, I, I, P]),
     "c2s_softmax_stitch": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "c2s_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P, F, P]),
     "c2s_fill": (I, [P, L, F, P]),

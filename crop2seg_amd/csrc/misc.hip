@@ -378,12 +378,13 @@ __global__ __launch_bounds__(64) void dw_wgrad_reduce_kernel(const float* __rest
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                      const float* __restrict__ cw, float* __restrict__ part, int B, int K,
                                                      int HW, float eps, long long ignore_index) {
-    __shared__ float red[4][2];
+    __shared__ float red[4][3];
     const long total = (long)B * HW;
-    float num = 0.f, den = 0.f;
+    float num = 0.f, den = 0.f, bad = 0.f;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long long yy = target[e];
-        if (yy == ignore_index || yy < 0 || yy >= K) continue;
+        if (yy == ignore_index) continue;
+        if (yy < 0 || yy >= K) { bad += 1.f; continue; }     // torch raises (device assert); here: skipped and counted
         const int y = (int)yy;
         const int pix = (int)(e % HW), b = (int)(e / HW);
         const float* lp = logits + (size_t)b * K * HW + pix;
@@ -402,21 +403,22 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         num += li;
         den += w;
     }
-    num = wave_sum(num); den = wave_sum(den);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = den; }
+    num = wave_sum(num); den = wave_sum(den); bad = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = den; red[threadIdx.x >> 6][2] = bad; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[blockIdx.x * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        part[blockIdx.x * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        part[blockIdx.x * 3] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[blockIdx.x * 3 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        part[blockIdx.x * 3 + 2] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
     }
 }
 
 __global__ void ce_finalize_kernel(const float* __restrict__ part, float* __restrict__ tot, float* __restrict__ loss,
                                    int blocks) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double num = 0, den = 0;
-    for (int i = 0; i < blocks; ++i) { num += part[i * 2]; den += part[i * 2 + 1]; }
-    tot[0] = (float)num; tot[1] = (float)den;
+    double num = 0, den = 0, bad = 0;
+    for (int i = 0; i < blocks; ++i) { num += part[i * 3]; den += part[i * 3 + 1]; bad += part[i * 3 + 2]; }
+    tot[0] = (float)num; tot[1] = (float)den; tot[2] = (float)bad;
     *loss = (float)(num / den);
 }
 
@@ -571,18 +573,18 @@ extern "C" int c2s_dwconv_wgrad(const float* in, const float* gout, float* parti
 
 extern "C" size_t c2s_cross_entropy_workspace_floats(int B, int HW) {
     (void)B; (void)HW;
-    return 2 * CE_BLOCKS + 2;
+    return 3 * CE_BLOCKS + 3;
 }
 
 extern "C" int c2s_cross_entropy(const float* logits, const int64_t* target, const float* class_w, float* loss,
                                  float* glogits, int B, int K, int HW, float label_smoothing, long long ignore_index,
                                  float* workspace, size_t ws_floats, void* stream) {
     C2S_REQUIRE(logits && target && class_w && loss && workspace, "cross_entropy: null pointer");
-    C2S_REQUIRE(ws_floats >= 2 * CE_BLOCKS + 2 && B > 0 && K > 0 && HW > 0, "cross_entropy: bad args");
+    C2S_REQUIRE(ws_floats >= 3 * CE_BLOCKS + 3 && B > 0 && K > 0 && HW > 0, "cross_entropy: bad args");
     C2S_REQUIRE(label_smoothing >= 0.f && label_smoothing <= 1.f, "cross_entropy: label_smoothing must be in [0, 1]");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = grid_for((long)B * HW, CE_BLOCKS);
-    float* tot = workspace + 2 * CE_BLOCKS;
+    float* tot = workspace + 3 * CE_BLOCKS;      // (sum, weight sum, targets outside [0,K) other than ignore_index)
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, target, class_w, workspace, B, K, HW,
                        label_smoothing, ignore_index);
     C2S_CHECK_LAUNCH("ce_fwd");

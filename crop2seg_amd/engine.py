@@ -997,6 +997,13 @@ def cross_entropy(logits: Tensor, target: Tensor, class_w: Tensor, ws: Workspace
     return loss, gl
 
 
+def bad_target_count(ws: Workspace) -> int:
+    """Targets outside [0, K) (other than ignore_index) the last cross_entropy call on this workspace met: torch's
+    CrossEntropyLoss raises on them, the kernel skips and counts them.  Reads a device value (host synchronisation)."""
+    w = ws.bufs.get("ce")
+    return 0 if w is None else int(float(w[w.numel() - 1]))
+
+
 def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float = 1e-3, b1: float = 0.9,
               b2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0, step_dev: Optional[Tensor] = None) -> None:
     check(lib().c2s_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps, step,

@@ -148,6 +148,12 @@ class TrainStep:
                 self.grads[n].zero_()
         return loss, logits
 
+    def bad_targets(self) -> int:
+        """Labels outside [0, num_classes) (other than ignore_index) in the last step's batch: torch's CrossEntropyLoss raises on
+        them, the loss kernel skips and counts them -- call this every display_step to surface a mislabelled dataset
+        (host synchronisation)."""
+        return E.bad_target_count(self.ws)
+
     def _fresh_dropout(self) -> Fn.DropoutState:
         drop = Fn.DropoutState()
         if self.model.training:

@@ -35,8 +35,14 @@ class SeriesCollator:
     `max_size` pads to a fixed T (pad_collate's max_size), else to the longest series of the batch."""
 
     def __init__(self, channels_order: Optional[Sequence[int]] = None, mean=None, std=None, pad_value: float = 0.0,
-                 device="cuda", max_size: Optional[int] = None, mode: str = "zero_copy", slots: int = 2):
+                 device="cuda", max_size: Optional[int] = None, mode: str = "zero_copy", slots: int = 2,
+                 add_ndvi: bool = False, ndvi_bands: Optional[Tuple[int, int]] = None):
+        """add_ndvi: append the dataset's NDVI channel (s2_ts_cz_crop.py:376-391,401-402): (NIR - red) / (NIR + red) of the RAW
+        bands, 0 where the sum is 0 or the quotient leaves [-1, 1]; not normalised; the model then takes input_dim + 1 channels
+        (train.py:315-316).  ndvi_bands = (NIR, red) as positions in the RE-ORDERED channel list, default (6, 2) with a
+        PASTIS-like order and (3, 0) otherwise, as in the reference."""
         assert mode in ("zero_copy", "staged")
+        self.add_ndvi, self.ndvi_bands = bool(add_ndvi), ndvi_bands
         self.order = list(channels_order) if channels_order is not None else None
         self.mean = None if mean is None else np.ascontiguousarray(np.asarray(mean, dtype=np.float32))
         self.std = None if std is None else np.ascontiguousarray(np.asarray(std, dtype=np.float32))
@@ -69,7 +75,11 @@ class SeriesCollator:
         T = self.max_size if self.max_size is not None else max(lengths)
         assert max(lengths) <= T
         order = self.order if self.order is not None else list(range(Cs))
-        Cc = len(order)
+        ndvi_a = ndvi_b = -1
+        if self.add_ndvi:
+            na, nb = self.ndvi_bands if self.ndvi_bands is not None else ((6, 2) if self.order is not None else (3, 0))
+            ndvi_a, ndvi_b = order[na], order[nb]              # positions in the re-ordered list -> source channels
+        Cc = len(order) + (1 if self.add_ndvi else 0)
         frame = Cs * H * W
         total = sum(lengths)
         slot = self._slots[self._next]
@@ -102,14 +112,14 @@ class SeriesCollator:
         x = torch.empty(B, T, Cc, H, W, device=self.device, dtype=torch.float32)
         dd = torch.empty(B, T, device=self.device, dtype=torch.int64)
         valid = torch.empty(B * T, device=self.device, dtype=torch.int32)
-        order_a = (C.c_int * Cc)(*order)
+        order_a = (C.c_int * len(order))(*order)
         mean_a = None if self.mean is None else self.mean.ctypes.data_as(C.POINTER(C.c_float))
         std_a = None if self.std is None else self.std.ctypes.data_as(C.POINTER(C.c_float))
         if self.mean is not None:
-            assert len(self.mean) == Cc and len(self.std) == Cc
-        check(lib().c2s_collate_series(src_ptr, _SRC[dt], meta_dev.data_ptr(), meta_dev.data_ptr() + 8 * (B + 1), x.data_ptr(),
-                                       dd.data_ptr(), valid.data_ptr(), B, T, Cc, Cs, H * W, order_a, mean_a, std_a,
-                                       self.pad_value, stream), "collate_series")
+            assert len(self.mean) == len(order) and len(self.std) == len(order)
+        check(lib().c2s_collate_series_ndvi(src_ptr, _SRC[dt], meta_dev.data_ptr(), meta_dev.data_ptr() + 8 * (B + 1), x.data_ptr(),
+                                            dd.data_ptr(), valid.data_ptr(), B, T, Cc, Cs, H * W, order_a, mean_a, std_a,
+                                            self.pad_value, ndvi_a, ndvi_b, stream), "collate_series")
         slot["meta_dev"] = meta_dev    # the device copy stays alive until this set is reused (after its event)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))

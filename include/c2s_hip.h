@@ -407,8 +407,9 @@ int c2s_temporal_aggregate_bwd(const c2s_agg_desc* d, const float* x, const floa
  * Loss + optimiser of the train step (train.py:454,463-468; src/learning/utils.py:314-328).
  *   c2s_cross_entropy: nn.CrossEntropyLoss(weight=w, label_smoothing=eps) (train.py:463-468), reduction "mean":
  *   loss = sum_i [(1-eps) w[y_i] nll_i + (eps/K) sum_k w[k] (-log p_ik)] / sum_i w[y_i] over the pixels whose target is not
- *   ignore_index (torch's default -100; targets outside [0,K) are skipped the same way -- torch raises instead); writes
- *   loss (1 float) and, if glogits != NULL, dL/dlogits.  workspace 2*blocks floats (see query).
+ *   ignore_index (torch's default -100; targets outside [0,K) are skipped the same way -- torch raises instead -- and COUNTED: the
+ *   last three floats of the workspace hold (sum, weight sum, number of such targets) after the call); writes
+ *   loss (1 float) and, if glogits != NULL, dL/dlogits.  workspace: see the query.
  *   c2s_adam_flat: torch.optim.Adam defaults on a flat parameter buffer.
  * ------------------------------------------------------------------------------------------------ */
 size_t c2s_cross_entropy_workspace_floats(int B, int HW);

@@ -156,16 +156,23 @@ def pad_tensor(x: torch.Tensor, l: int, pad_value=0) -> torch.Tensor:
 
 
 def collate_series(series: Sequence[np.ndarray], dates: Sequence[np.ndarray], channels_order: Sequence[int],
-                   mean: Optional[np.ndarray], std: Optional[np.ndarray], pad_value=0):
+                   mean: Optional[np.ndarray], std: Optional[np.ndarray], pad_value=0, add_ndvi: bool = False,
+                   ndvi_bands=(6, 2)):
     """__getitem__ tail (astype(float32) -> channel re-order -> (d - mean) / std in fp32) for every series, then
     pad_collate of the (data, dates) pairs: returns x [B,T,C,H,W] f32, dates [B,T] int64."""
     xs, ds = [], []
     for a, d in zip(series, dates):
         t = torch.from_numpy(a.astype(np.float32))[:, list(channels_order), ...]
+        if add_ndvi:                       # s2_ts_cz_crop.py:376-391: on the re-ordered RAW bands, before the normalisation
+            na, nb = ndvi_bands
+            ndvi = torch.where(t[:, na] + t[:, nb] == 0, 0., (t[:, na] - t[:, nb]) / (t[:, na] + t[:, nb]))
+            ndvi = torch.where((ndvi < -1) | (ndvi > 1), 0, ndvi)
         if mean is not None:
             m = torch.from_numpy(np.asarray(mean)).float()
             s = torch.from_numpy(np.asarray(std)).float()
             t = (t - m[None, :, None, None]) / s[None, :, None, None]
+        if add_ndvi:                       # :401-402: appended after the normalisation, itself not normalised
+            t = torch.cat([t, ndvi[:, None]], dim=1)
         xs.append(t)
         ds.append(torch.from_numpy(np.asarray(d)).long())
     m_ = max(t.shape[0] for t in xs)

@@ -148,3 +148,16 @@ def test_get_model_mapping():
     assert isinstance(get_model(default_config("timeunet")), C2S.TimeUNet_v1)
     m = get_model(default_config("utae"))
     assert m.spec.out_conv == [32, 15] and m.spec.padding_mode == "reflect"
+
+
+@pytest.mark.gpu
+def test_wgrad_winograd_launches_without_c2s_init():
+    """c2s_conv_wgrad's Winograd branch needs the raised dynamic-LDS limit; a caller that never ran c2s_init
+    (fresh process, raw ctypes) must still get a working launch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "abi_noinit_worker.py")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ABI_NOINIT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -99,6 +99,15 @@ def test_cross_entropy_label_smoothing_and_ignore(eps, ignore):
                                label_smoothing=eps)
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
     assert float((gl.cpu() - logits.grad).norm() / logits.grad.norm()) <= 1e-5
+    ws = E.Workspace(torch.device("cuda"))
+    ybad = y.clone()
+    ybad[0, 0, :3] = 15                       # torch raises on these; the kernel skips and counts them
+    ybad[1, 1, 1] = -7
+    keep = (ybad >= 0) & (ybad < 15) | (ybad == -100)
+    loss2, _ = E.cross_entropy(logits.detach().cuda(), ybad.cuda(), cw.cuda(), ws, False, label_smoothing=eps)
+    ref2 = torch.nn.functional.cross_entropy(logits.detach(), torch.where(keep, ybad, torch.full_like(ybad, -100)), weight=cw,
+                                             label_smoothing=eps)
+    assert E.bad_target_count(ws) == 4 and abs(float(loss2) - float(ref2)) <= 1e-5 * abs(float(ref2))
 
 
 @pytest.mark.parametrize("dtype", [np.int16, np.uint16, np.float32])
@@ -308,3 +317,23 @@ def test_step_meters_test_region_and_boundary_meter(region):
     cb = TO.confusion_matrix(out_b.argmax(1).numpy(), TO.boundary_target(y, K).numpy(), 2)
     assert np.array_equal(m.iou_boundary.conf_metric.conf.cpu().numpy(), 2 * cb)
     assert m.get_miou_acc() == TO.miou_acc(2 * rc, -1) and m.get_miou_acc_boundary() == TO.miou_acc(2 * cb, None)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.float32])
+def test_collate_series_with_ndvi_channel(dtype):
+    """add_ndvi (s2_ts_cz_crop.py:376-391,401-402): the NDVI of the raw bands as an eleventh, un-normalised channel -- bit-exact
+    against the restatement, including pixels whose band sum is 0 and quotients outside [-1, 1] (negative reflectances)."""
+    from crop2seg_amd.utils import CHANNELS_LIKE_PASTIS, SeriesCollator
+    rng = np.random.default_rng(3)
+    lengths = [4, 6, 2]
+    series = [rng.integers(-300, 9000, (t, 10, 32, 32)).astype(dtype) for t in lengths]
+    for s in series:
+        s[0, :, :4, :4] = 0                                  # no-data corner: band sum 0 -> NDVI 0
+        s[-1, 3, 5, 5], s[-1, 2, 5, 5] = 10, -30             # NIR + red < 0, quotient -2 -> clipped to 0
+    dates = [np.sort(rng.integers(1, 400, t)).astype(np.int64) for t in lengths]
+    mean, std = rng.normal(1200, 300, 10), rng.uniform(300, 900, 10)
+    coll = SeriesCollator(CHANNELS_LIKE_PASTIS, mean, std, add_ndvi=True)
+    x, dd, valid = coll(series, dates)
+    rx, rd = TO.collate_series(series, dates, CHANNELS_LIKE_PASTIS, mean, std, add_ndvi=True)
+    assert x.shape == (3, 6, 11, 32, 32) and torch.equal(x.cpu(), rx) and torch.equal(dd.cpu(), rd)
+    assert float(x[:, :, 10].abs().max()) <= 1.0 and float(x[0, 0, 10, :4, :4].abs().max()) == 0.0
