@@ -132,9 +132,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
     // reflect adjoint: per-lane masks of the border positions this lane owns
     float mxlo[2] = {0.f, 0.f}, mxhi[2] = {0.f, 0.f}, mylo[2] = {0.f, 0.f}, myhi[2] = {0.f, 0.f};
-    bool wave_x = false, wave_y = false;
     if constexpr (ADJ) {
-        bool anyx = false, anyy = false;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int f = 2 * wave + q;
@@ -143,11 +141,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             mxhi[q] = ox == p.ax_hi ? 1.f : 0.f;
             mylo[q] = oy == p.ay_lo ? 1.f : 0.f;
             myhi[q] = oy == p.ay_hi ? 1.f : 0.f;
-            anyx = anyx || ox == p.ax_lo || ox == p.ax_hi;
-            anyy = anyy || oy == p.ay_lo || oy == p.ay_hi;
         }
-        wave_x = __any(anyx);
-        wave_y = __any(anyy);
     }
 
     f32x16 acc[MF][2];
@@ -221,11 +215,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 // fold of the reflected halo: fixed offsets +-(K-1), always inside the staged tile
                 constexpr int D = K - 1;
                 const bool xl = kx == K - 1, xh = kx == 0, yl = ky == K - 1, yh = ky == 0;
-                if ((xl || xh) && wave_x) {
+                if (xl || xh) {                      // branch-free (0 / 1 lane masks): see conv_xpair.hip
                     const float mx = xl ? mxlo[q] : mxhi[q];
                     v = fmaf(mx, Xl[ad + (xl ? -D : D)], v);
                 }
-                if ((yl || yh) && wave_y) {
+                if (yl || yh) {
                     const float my = yl ? mylo[q] : myhi[q];
                     const int dy = (yl ? -D : D) * cols;
                     v = fmaf(my, Xl[ad + dy], v);

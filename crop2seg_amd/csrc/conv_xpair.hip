@@ -102,14 +102,11 @@ __global__ __launch_bounds__(256) void conv_xpair_kernel(XpParams p) {
     const int aoff = lk * COT + li;
 
     float mylo = 0.f, myhi = 0.f, mx[2] = {0.f, 0.f};
-    bool wave_x = false, wave_y = false;
     if constexpr (ADJ) {
         mylo = oy == p.ay_lo ? 1.f : 0.f;
         myhi = oy == p.ay_hi ? 1.f : 0.f;
         mx[0] = ox == p.Wout - 1 ? 1.f : 0.f;
         mx[1] = ox == 0 ? 1.f : 0.f;
-        wave_x = __any(ox == p.Wout - 1 || ox == 0);
-        wave_y = __any(oy == p.ay_lo || oy == p.ay_hi);
     }
 
     f32x16 acc[MF][2];
@@ -167,16 +164,18 @@ __global__ __launch_bounds__(256) void conv_xpair_kernel(XpParams p) {
             const int ad = boff + 2 * cp * plane + ty * cols + tx + q;       // tile column 0 = sub-grid column j-1
             float v = Xc[ad];
             if constexpr (ADJ) {
-                // adjoint of the reflection: the halo tap folds back onto the neighbouring input (offset +-1)
+                // adjoint of the reflection: the halo tap folds back onto the neighbouring input (offset +-1).  Branch-free:
+                // the 0 / 1 lane masks select, every extra element lies inside the staged tile (finite data).  With
+                // wave-uniform branches here (round 1-2: `if (wave_x)`, `if (wave_y)`) the basic-block boundaries kept the
+                // operand reads of the next k-step from being scheduled under the MFMAs: +110 us on the 64 -> 64 @128x128
+                // data gradient (tools/xpair_bench.py).
                 const bool xr_ = (q == 0 && tx == 0) || (q == 1 && tx == 1);
                 const int dx = q == 0 ? 1 : -1;
-                if (xr_ && wave_x) v = fmaf(mx[q], Xc[ad + dx], v);
-                if (wave_y) {
-                    const float my = ty == 1 ? mylo : myhi;
-                    const int dy = (ty == 1 ? -1 : 1) * cols;
-                    v = fmaf(my, Xc[ad + dy], v);
-                    if (xr_) v = fmaf(my * mx[q], Xc[ad + dy + dx], v);
-                }
+                const float my = ty == 1 ? mylo : myhi;
+                const int dy = (ty == 1 ? -1 : 1) * cols;
+                if (xr_) v = fmaf(mx[q], Xc[ad + dx], v);
+                v = fmaf(my, Xc[ad + dy], v);
+                if (xr_) v = fmaf(my * mx[q], Xc[ad + dy + dx], v);
             }
             b[q] = v;
         }
