@@ -1,0 +1,460 @@
+// 3x3 stride-1 pad-1 convolution (forward and data gradient) as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32, with the
+// OUTPUT TRANSFORM IN REGISTERS: every lane holds all 16 transform-domain values of its (output channels, 2x2 block), so the
+// epilogue needs no exchange between waves.
+//
+//   Y(2x2 block) = At [ (G g Gt) (.) (Bt d B) ] A        M[p][o][t] = sum_c U[p][c][o] * V[p][c][t],  p = 4 xi + nu
+//
+// conv_winograd.hip gives wave xi one ROW of the 4x4 transform domain (8 accumulators of 32x32), so the xi-sum of the output
+// transform crosses waves: three LDS barriers and a 64 KB exchange per tile (10.5 k of its 56 k cycles per tile, with the MFMA
+// pipe of that workgroup idle; tools/wino_stamps.py).  Here a wave owns all 16 points of 32 OUTPUT CHANNELS x 16 BLOCKS:
+//   workgroup = 8 waves on one tile of 64 blocks (8 x 32 output pixels) x 64 output channels; wave w: channels 32 (w & 1) ..,
+//   block row w >> 1;  accumulators acc[16 points][2 channel groups] of 16x16 = 128 VGPRs
+//   A operand = U[p][c][o]   lane (o = lane & 15, k = lane >> 4): the 16 points of one (c, o) are 16 consecutive floats in LDS
+//                            (pitch 20 floats: four conflict-free ds_read_b128)
+//   B operand = V[p][c][t]   lane (t = lane & 15 = block column, k = lane >> 4) transforms the WHOLE 4x4 patch of its (block,
+//                            channel): four ds_read2_b64, 16 packed VALU ops (v_pk_add_f32), used by 32 MFMAs
+//   D                        lane (t, q): channels 4q .. 4q+3 of block t, for all 16 points -> At M A in registers, one float2
+//                            per output row (16 lanes = 128 contiguous bytes)
+// tools/_diag/mfma_rate.hip: on this chip every VALU instruction of a wave costs the SIMD ~8 cycles of MFMA issue (a 16x16x4
+// fp32 MFMA is 32), whichever wave it comes from -- so the budget is VALU instructions per MFMA: 0.5 here (a first version
+// with 16 channels x 32 blocks per wave and scalar adds had 2.5 and ran at the 4-wave kernel's speed).
+// Operands arrive by LDS-DMA (U: global_load_lds_dwordx4 of a slab packed lane-linear; raw tile: buffer_load_dword ... lds,
+// one gathered float per lane) into THREE buffers: the requests run two chunks ahead of the MFMAs across tile boundaries, and
+// the single barrier per chunk sits in its middle, so no wave waits at a barrier for data and the first operand reads of a
+// chunk are in flight during the last MFMAs of the chunk before.  Persistent workgroups, one per CU.
+// Data gradient of the reflect-padded convolution: the adjoint folds onto the raw patch of the border blocks (top: d3 += d1,
+// bottom: d0 += d2, left: col3 += col1, right: col0 += col2), only in the waves / tiles that touch a border (uniform branches).
+//
+// Reference call sites replaced: as conv_winograd.hip (nn.Conv2d 3x3: src/backbones/conv.py:70-80,378-382 and its
+// convolution_backward-input incl. reflection_pad2d_backward).  Planes at least 32 pixels wide; narrower ones stay with the
+// 4-wave kernel.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct Wino16Params {
+    const float* src0;
+    const float* src1;
+    const float* upk;      // [cout block][chunk][8 c][64 o][20] (16 points + 4 pad)
+    const float* bias;
+    float* out;
+    const int* valid;
+    int C0, C1, H, W, Cout, CoutP;
+    int pad_mode, accumulate;
+    int N, tiles, tiles_x, nchunks;
+};
+
+constexpr int W16_CK = 8;
+constexpr int W16_UP = 20;                          // floats per (c, o): 16 points + 4 (bank-conflict-free b128 reads)
+constexpr int W16_USLAB = W16_CK * 64 * W16_UP;     // 10,240 floats = 40 KB per chunk
+constexpr int W16_BR = 4, W16_BC = 16;              // blocks per tile: 4 rows x 16 columns = 8 x 32 output pixels
+constexpr int W16_RR = 2 * W16_BR + 2, W16_RC = 2 * W16_BC + 2;     // raw tile 10 x 34
+constexpr int W16_PLANE = W16_RR * W16_RC;          // 340
+constexpr int W16_XP = 352;                         // LDS pitch per channel (= 32 mod 64 banks: the four k groups of a wave do not collide)
+constexpr int W16_MAXE = 6;                         // raw-tile LDS-DMA pieces per thread (one float each)
+constexpr int W16_XS = W16_MAXE * 512;              // 3,072 floats: 8 x 352 and a zero-filled tail
+constexpr int W16_BUF = W16_USLAB + W16_XS;         // 13,312 floats = 52 KB; three buffers = 156 KB
+constexpr int W16_WPT = W16_USLAB / 4 / 512;        // 5 LDS-DMA pieces per thread
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// tools/wino16_diag.py builds diagnostic copies with one part of the kernel removed (results are then wrong by design):
+//   1 = no MFMA, 2 = no staging after the first two chunks, 3 = no output stores, 4 = no LDS operand reads in the K loop,
+//   5 = 2 and 4 together (MFMA + transform + epilogue only), 6 = 5 without the barrier per chunk, 7 = 5 without the transforms,
+//   8 = no raw-tile staging, 9 = no U staging, 10 = every raw tile from frame 0 (L2 hits)
+#ifndef C2S_W16_DIAG
+#define C2S_W16_DIAG 0
+#endif
+#define C2S_AS1 __attribute__((address_space(1)))
+#define C2S_AS3 __attribute__((address_space(3)))
+
+template <bool ADJ>
+__global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: row masks and bases in SGPRs)
+    const int t = lane & 15, kq = lane >> 4;        // block column / k index (B, D: channel quad) ; A: output channel / k index
+    const int ch = w & 1, brow = w >> 1;            // channel half (32) and block row of this wave
+    const int co0 = blockIdx.y * 64;
+    const int HW = p.H * p.W;
+    const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
+    const int ntotal = p.N * p.tiles;
+    const int K = p.nchunks;
+
+    auto next_valid = [&](int tt) {
+        while (tt < ntotal && p.valid != nullptr && p.valid[tt / p.tiles] == 0) tt += gridDim.x;
+        return tt;
+    };
+    auto tile_origin = [&](int tt, int& n, int& oy0, int& ox0) {
+        n = tt / p.tiles;
+        const int ti = tt - n * p.tiles;
+        const int tyi = ti / p.tiles_x, txi = ti - tyi * p.tiles_x;
+        oy0 = tyi * 2 * W16_BR; ox0 = txi * 2 * W16_BC;
+    };
+
+    // ---- the staging side runs two chunks ahead of the MFMAs, across tile boundaries: its own tile state
+    int goff[W16_MAXE];
+    int diag_staged = 0;
+    int scand = 0, cflag = 1;                          // the tile after the staging tile and its frame's flag (fetched a tile ahead)
+    __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src0, 0, 0, 0x00020000), r1 = r0;
+    auto begin_staging = [&](int tt) {
+        int n, oy0, ox0;
+        tile_origin(tt, n, oy0, ox0);
+        if (C2S_W16_DIAG == 10) n = 0;
+#pragma unroll
+        for (int i = 0; i < W16_MAXE; ++i) {              // LDS float e = tid + 512 i of the raw tile: (channel, row, col)
+            const int e = tid + i * 512;
+            const int c = e / W16_XP, rem = e - c * W16_XP;
+            int gy = oy0 - 1 + rem / W16_RC, gx = ox0 - 1 + rem % W16_RC;
+            const bool ok = rem < W16_PLANE && c < W16_CK &&
+                            (reflect ? (gy <= p.H && gx <= p.W) : (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W));
+            gy = reflect_idx(gy, p.H);                    // (identity inside the plane)
+            gx = reflect_idx(gx, p.W);
+            goff[i] = ok ? ((c * HW + gy * p.W + gx) * 4) : -1;
+        }
+        scand = tt + gridDim.x;
+        cflag = (p.valid != nullptr && scand < ntotal) ? p.valid[scand / p.tiles] : 1;    // used K chunks from now
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
+        const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
+        r0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HW * 4, 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(s1n != nullptr ? s1n : s0n), 0, p.C1 * HW * 4, 0x00020000);
+    };
+    // both operands by LDS-DMA.  U: 40 KB per chunk, packed lane-linear.  Raw tile: one float per lane and piece, lane-linear in
+    // LDS, gathered (reflected) global addresses; out-of-range offsets (-1: zero padding, tile overhang, the tail) read as 0
+    const float* ublock = p.upk + (size_t)blockIdx.y * K * W16_USLAB + tid * 4;
+    auto stage_u = [&](int k, int buf) {
+        float* Wd = lds + buf * W16_BUF + tid * 4;
+        const float* g = ublock + (size_t)k * W16_USLAB;
+#pragma unroll
+        for (int i = 0; i < W16_WPT; ++i)
+            if (C2S_W16_DIAG != 9 || diag_staged < 2)
+                __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 2048), (C2S_AS3 void*)(Wd + i * 2048), 16, 0, 0);
+    };
+    auto stage_raw = [&](int k, int buf) {
+        if (C2S_W16_DIAG == 8 && diag_staged >= 2) return;
+        const int cb_ = k * W16_CK;
+        const bool first = cb_ < p.C0;
+        const int chan0 = (first ? cb_ : cb_ - p.C0) * HW * 4;
+        float* Xd = lds + buf * W16_BUF + W16_USLAB + (tid & ~63);
+#pragma unroll
+        for (int i = 0; i < W16_MAXE; ++i) {
+            const int off = goff[i] >= 0 ? goff[i] + chan0 : -1;
+            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (C2S_AS3 void*)(Xd + i * 512), 4, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (C2S_AS3 void*)(Xd + i * 512), 4, off, 0, 0, 0);
+        }
+    };
+    // XCD-aware start (as conv_winograd.hip): each XCD walks a contiguous eighth of the tiles in flight
+    const int wg0 = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    int tile = next_valid(wg0);
+    if (tile >= ntotal) return;
+    int stile = tile, sk = 0;                          // next chunk to stage: chunk sk of tile stile (stile >= ntotal: none left)
+    begin_staging(stile);
+    // the two halves of one chunk's requests (uniform across the workgroup): the raw tile (HBM latency) first, U (L2) later
+    const bool diag_stage = (C2S_W16_DIAG != 2 && C2S_W16_DIAG < 5);
+    auto stage_next_raw = [&](int buf) {
+        if (stile < ntotal && (diag_stage || diag_staged < 2)) stage_raw(sk, buf);
+    };
+    auto stage_next_u = [&](int buf) {
+        if (stile >= ntotal) return;
+        if (diag_stage || diag_staged < 2) stage_u(sk, buf);
+        ++diag_staged;
+        if (++sk == K) {                               // once per multiplied tile (K >= 3), at its chunk K - 3
+            sk = 0;
+            stile = __builtin_amdgcn_readfirstlane(cflag) != 0 ? scand : next_valid(scand + gridDim.x);
+            if (stile < ntotal) begin_staging(stile);
+        }
+    };
+    int cur = 0;                                       // buffer of the chunk being multiplied (three buffers in rotation)
+    stage_next_raw(0); stage_next_u(0);
+    stage_next_raw(1); stage_next_u(1);
+
+    // LDS offsets of this lane's operands inside a buffer
+    const int aoff = (kq * 64 + 32 * ch + t) * W16_UP;                          // + s * 4 * 64 * UP + mt * 16 * UP
+    const int boff = W16_USLAB + kq * W16_XP + (2 * brow) * W16_RC + 2 * t;     // + s * 4 * XP + r * RC
+    auto load_a = [&](const float* ab, int s, int mt, float (&a)[16]) {
+        if ((C2S_W16_DIAG >= 4) && ab != lds + aoff) return;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ab + (s * 4 * 64 + mt * 16) * W16_UP + 4 * q4);
+            a[4 * q4] = v[0]; a[4 * q4 + 1] = v[1]; a[4 * q4 + 2] = v[2]; a[4 * q4 + 3] = v[3];
+        }
+    };
+    int boff0 = boff, boff1 = boff + 4 * W16_XP;       // (the two k-steps; opaque, so that the row offsets stay ds_read2 immediates)
+    asm volatile("" : "+v"(boff0), "+v"(boff1));
+    auto load_d = [&](const float* bufp, int s, f32x2 (&dl)[4], f32x2 (&dh)[4]) {     // patch rows as (cols 0,1), (cols 2,3)
+        if ((C2S_W16_DIAG >= 4) && bufp != lds) return;
+        const float* bb = bufp + (s ? boff1 : boff0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dl[r] = *reinterpret_cast<const f32x2*>(bb + r * W16_RC);
+            dh[r] = *reinterpret_cast<const f32x2*>(bb + r * W16_RC + 2);
+        }
+    };
+    // adjoint folds of this wave's block row (scalar) and of this lane's block column
+    float mtop = 0.f, mbot = 0.f;
+    f32x2 mright = {0.f, 0.f}, mleft = {0.f, 0.f};     // (right, 0) and (0, left)
+    bool rowfold = false, colfold = false;
+    // V = Bt d B of one patch in 16 packed adds: rows on the column pairs, then per row xi (v0, v3) = L - H and
+    // (v1, v2) = (L.y + H.x, H.x - L.y) (one VOP3P with operand selects); the s_nop covers the VALU -> MFMA wait states,
+    // which the compiler cannot see through the asm
+    auto transform = [&](const f32x2 (&dl_)[4], const f32x2 (&dh_)[4], float (&V)[16]) {
+        f32x2 dl[4], dh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dl[r] = dl_[r]; dh[r] = dh_[r]; }
+        if constexpr (ADJ) {
+            if (rowfold) {
+                dl[3] += mtop * dl[1]; dh[3] += mtop * dh[1];
+                dl[0] += mbot * dl[2]; dh[0] += mbot * dh[2];
+            }
+            if (colfold) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x2 lo = dl[r], hi = dh[r];
+                    dl[r] = lo + __builtin_shufflevector(hi, hi, 0, 0) * mright;     // col0 += right * col2
+                    dh[r] = hi + __builtin_shufflevector(lo, lo, 1, 1) * mleft;      // col3 += left * col1
+                }
+            }
+        }
+        // (one asm block: left to itself the compiler unpacks part of this into scalar adds, and every VALU instruction costs
+        // MFMA issue time; tl/th are scratch)
+        f32x2 p03[4], p12[4], tl[4], th[4];
+        asm("v_pk_add_f32 %8, %16, %18 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %9, %17, %18\n\t"
+            "v_pk_add_f32 %10, %18, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %11, %17, %19 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %12, %20, %22 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %13, %21, %22\n\t"
+            "v_pk_add_f32 %14, %22, %21 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %15, %21, %23 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %0, %8, %12 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %8, %12 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %1, %9, %13 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %5, %9, %13 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %2, %10, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %6, %10, %14 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %3, %11, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %7, %11, %15 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+            "s_nop 1"
+            : "=&v"(p03[0]), "=&v"(p03[1]), "=&v"(p03[2]), "=&v"(p03[3]), "=&v"(p12[0]), "=&v"(p12[1]), "=&v"(p12[2]), "=&v"(p12[3]),
+              "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]), "=&v"(th[0]), "=&v"(th[1]), "=&v"(th[2]), "=&v"(th[3])
+            : "v"(dl[0]), "v"(dl[1]), "v"(dl[2]), "v"(dl[3]), "v"(dh[0]), "v"(dh[1]), "v"(dh[2]), "v"(dh[3]));
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            V[4 * xi] = p03[xi][0]; V[4 * xi + 1] = p12[xi][0]; V[4 * xi + 2] = p12[xi][1]; V[4 * xi + 3] = p03[xi][1];
+        }
+    };
+    f32x4 acc[16][2];
+    auto mma = [&](const float (&a)[16], const float (&V)[16], int mt) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+#if C2S_W16_DIAG == 1
+            asm volatile("" ::"v"(a[q]), "v"(V[q]));
+#else
+            acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], acc[q][mt], 0, 0, 0);
+#endif
+        }
+    };
+
+    // Schedule of one chunk: four half-steps (k-step s, channel group mt) of 16 MFMAs; the LDS reads of a half-step are issued
+    // one half-step ahead (sched_barrier keeps the compiler from sinking them back to their use):
+    //   (0,0) (0,1) | barrier (everyone's LDS-DMA of the NEXT chunk has landed: issued one chunk ago; everyone has left the
+    //   PREVIOUS chunk's buffer) | request the chunk after next into that buffer | (1,0) | first reads of the next chunk | (1,1)
+    float a0[16], a1[16], V[16];
+    f32x2 dl[4], dh[4], el[4], eh[4];
+    const int cof = co0 + 32 * ch + 4 * kq;            // this lane's output channels: cof + 16 mt + r (D rows 4 kq + r)
+    // bias: At e11 A = [[1,1],[1,1]], so a tile's accumulators of point (1,1) start at the bias (64 floats behind the buffers)
+    float* lbias = lds + 3 * W16_BUF;
+    if (tid < 64) lbias[tid] = (p.bias != nullptr && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
+    __syncthreads();                                  // (drains the first chunk's LDS-DMA: vmcnt(0))
+    load_a(lds + aoff, 0, 0, a0);
+    load_d(lds, 0, dl, dh);
+    while (true) {
+        int n, oy0, ox0;
+        tile_origin(tile, n, oy0, ox0);
+        if constexpr (ADJ) {
+            const int gbx = (ox0 >> 1) + t, gby = (oy0 >> 1) + brow, lastx = (p.W >> 1) - 1, lasty = (p.H >> 1) - 1;
+            mleft = (f32x2){0.f, gbx == 0 ? 1.f : 0.f};
+            mright = (f32x2){gbx == lastx ? 1.f : 0.f, 0.f};
+            mtop = gby == 0 ? 1.f : 0.f;
+            mbot = gby == lasty ? 1.f : 0.f;
+            rowfold = gby == 0 || gby == lasty;
+            colfold = ox0 == 0 || (ox0 >> 1) + W16_BC > lastx;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[q][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[5][mt] = *reinterpret_cast<const f32x4*>(lbias + 32 * ch + 16 * mt + 4 * kq);
+        for (int k = 0; k < K; ++k) {
+            const int nb = cur == 2 ? 0 : cur + 1, fb = nb == 2 ? 0 : nb + 1;
+            const float* ab = lds + cur * W16_BUF + aoff;
+            const float* bb = lds + cur * W16_BUF;
+            load_a(ab, 0, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (C2S_W16_DIAG != 7 || k == 0) transform(dl, dh, V);
+            __builtin_amdgcn_sched_barrier(0);
+            load_d(bb, 1, el, eh);                     // (after the transform: its temporaries are dead)
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, V, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(ab, 1, 0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, V, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (C2S_W16_DIAG != 6) __syncthreads();
+            stage_next_raw(fb);
+            load_a(ab, 1, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (C2S_W16_DIAG != 7) transform(el, eh, V);
+            mma(a0, V, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_next_u(fb);
+            load_a(lds + nb * W16_BUF + aoff, 0, 0, a0);       // (after the last chunk of the last tile: stale, unused)
+            load_d(lds + nb * W16_BUF, 0, dl, dh);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, V, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nb;
+        }
+        // ---- epilogue: At M A per (channel, block) in registers; lane (t, kq): channels cof + 16 mt + r, block (brow, t)
+        const int oy = oy0 + 2 * brow, ox = ox0 + 2 * t;
+        float* on = p.out + (size_t)n * p.Cout * HW;
+        const int H_ = p.H, W_ = p.W;
+        const bool in0 = ox < W_ && oy < H_, in1 = ox < W_ && oy + 1 < H_;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x2 y[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float P[4][2];
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    const float m0 = acc[4 * xi][mt][r], m1 = acc[4 * xi + 1][mt][r], m2 = acc[4 * xi + 2][mt][r], m3 = acc[4 * xi + 3][mt][r];
+                    P[xi][0] = m0 + m1 + m2;
+                    P[xi][1] = m1 - m2 - m3;
+                }
+                y[r][0] = (f32x2){P[0][0] + P[1][0] + P[2][0], P[0][1] + P[1][1] + P[2][1]};
+                y[r][1] = (f32x2){P[1][0] - P[2][0] - P[3][0], P[1][1] - P[2][1] - P[3][1]};
+            }
+            const int cq = cof + 16 * mt;
+            float* row0 = on + (size_t)cq * HW + (size_t)oy * W_ + ox;
+            if (p.accumulate) {                        // all eight reads in flight before the first add
+                f32x2 o[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool okc = cq + r < p.Cout;
+                    o[r][0] = okc && in0 ? *reinterpret_cast<const f32x2*>(row0 + (size_t)r * HW) : (f32x2){0.f, 0.f};
+                    o[r][1] = okc && in1 ? *reinterpret_cast<const f32x2*>(row0 + (size_t)r * HW + W_) : (f32x2){0.f, 0.f};
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { y[r][0] += o[r][0]; y[r][1] += o[r][1]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool okc = cq + r < p.Cout && (C2S_W16_DIAG != 3 || oy < 0);
+                if (okc && in0) *reinterpret_cast<f32x2*>(row0 + (size_t)r * HW) = y[r][0];
+                if (okc && in1) *reinterpret_cast<f32x2*>(row0 + (size_t)r * HW + W_) = y[r][1];
+            }
+        }
+        if (stile >= ntotal) break;
+        tile = stile;
+    }
+}
+
+struct TapTable9w {
+    int off[9];
+};
+
+// U = G g Gt of the 3x3 filter g[k] = src[o*so + c*sc + tap[k]], stored [cout block][chunk][c 8][o 64][20]
+__global__ void pack_winograd16_kernel(const float* __restrict__ src, float* __restrict__ upk, int cin, int cout, int coutP,
+                                       long so, long sc, TapTable9w tt) {
+    const int nchunks = (cin + W16_CK - 1) / W16_CK;
+    const long total = (long)nchunks * W16_CK * coutP;
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int o = (int)(e % coutP), c = (int)(e / coutP);
+    const bool real = o < cout && c < cin;
+    float g[3][3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = real ? src[o * so + c * sc + tt.off[k]] : 0.f;
+    float tmp[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        tmp[0][j] = g[0][j];
+        tmp[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        tmp[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        tmp[3][j] = g[2][j];
+    }
+    float* base = upk + (((size_t)(o >> 6) * nchunks + (c >> 3)) * W16_CK + (c & 7)) * 64 * W16_UP + (size_t)(o & 63) * W16_UP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        base[i * 4 + 0] = tmp[i][0];
+        base[i * 4 + 1] = 0.5f * (tmp[i][0] + tmp[i][1] + tmp[i][2]);
+        base[i * 4 + 2] = 0.5f * (tmp[i][0] - tmp[i][1] + tmp[i][2]);
+        base[i * 4 + 3] = tmp[i][2];
+    }
+#pragma unroll
+    for (int i = 16; i < W16_UP; ++i) base[i] = 0.f;
+}
+
+void init_hook() {
+    C2S_RAISE_LDS((conv_winograd16_kernel<false>));
+    C2S_RAISE_LDS((conv_winograd16_kernel<true>));
+}
+C2sInitRegistrar registrar(init_hook);
+
+}  // namespace
+
+extern "C" size_t c2s_winograd16_packed_floats(int cin, int coutP) {
+    return (size_t)((cin + W16_CK - 1) / W16_CK) * W16_CK * coutP * W16_UP;
+}
+
+extern "C" int c2s_pack_weights_winograd16(const float* src, float* upk, int cin, int cout, int coutP, long stride_o,
+                                           long stride_c, const int* host_tap_off, void* stream) {
+    C2S_REQUIRE(src && upk && host_tap_off && cin > 0 && cout > 0 && coutP % 64 == 0 && coutP >= cout, "pack_winograd16: bad args");
+    TapTable9w tt;
+    for (int i = 0; i < 9; ++i) tt.off[i] = host_tap_off[i];
+    const long total = (long)((cin + W16_CK - 1) / W16_CK) * W16_CK * coutP;
+    hipLaunchKernelGGL(pack_winograd16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, upk, cin, cout,
+                       coutP, stride_o, stride_c, tt);
+    C2S_CHECK_LAUNCH("pack_winograd16");
+    return C2S_OK;
+}
+
+extern "C" int c2s_conv3x3_winograd16_supported(const c2s_conv_desc* d) {
+    return d && d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Hin % 2 == 0 && d->Win % 2 == 0 &&
+           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 2 * W16_CK && (d->C1 == 0 || d->C0 % W16_CK == 0);
+}
+
+extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
+                                      const float* bias, float* out, const int* valid, void* stream) {
+    C2S_REQUIRE(d && src0 && upk && out, "conv3x3_winograd16: null pointer");
+    C2S_REQUIRE(c2s_conv3x3_winograd16_supported(d), "conv3x3_winograd16: 3x3 stride 1 pad 1, even planes at least 32 wide and 8 high, CoutP %% 64");
+    C2S_REQUIRE(d->N > 0 && d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0 || src1), "conv3x3_winograd16: bad channels");
+    C2S_REQUIRE(d->Hout == d->Hin && d->Wout == d->Win && d->OutH == d->Hout && d->OutW == d->Wout && d->osy == 1 &&
+                d->osx == 1 && d->ooy == 0 && d->oox == 0, "conv3x3_winograd16: dense same-size output only");
+    C2S_REQUIRE(d->CoutP >= d->Cout && d->Cout > 0, "conv3x3_winograd16: bad CoutP");
+    C2S_REQUIRE((long)(d->C0 > d->C1 ? d->C0 : d->C1) * d->Hin * d->Win * 4 < (1L << 31), "conv3x3_winograd16: frame too large");
+    if (d->reflect_adjoint) C2S_REQUIRE(d->pad_mode == C2S_PAD_ZEROS, "conv3x3_winograd16: the reflect adjoint is a zero-padded launch");
+    Wino16Params p;
+    p.src0 = src0; p.src1 = src1; p.upk = upk; p.bias = bias; p.out = out; p.valid = valid;
+    p.C0 = d->C0; p.C1 = d->C1; p.H = d->Hin; p.W = d->Win; p.Cout = d->Cout; p.CoutP = d->CoutP;
+    p.pad_mode = d->pad_mode; p.accumulate = d->accumulate;
+    p.tiles_x = cdiv(d->Win, 2 * W16_BC);
+    p.tiles = p.tiles_x * cdiv(d->Hin, 2 * W16_BR);
+    p.N = d->N;
+    p.nchunks = cdiv(d->C0 + d->C1, W16_CK);
+    const int cus = c2s_cus();                     // (runs the init hooks: dynamic LDS limit)
+    const int cblocks = d->CoutP / 64;
+    const long ntotal = (long)d->N * p.tiles;
+    long gx = ((long)cus + cblocks - 1) / cblocks;  // persistent: one 8-wave workgroup per CU
+    if (gx > ntotal) gx = ntotal;
+    dim3 grid((unsigned)gx, cblocks, 1);
+    const size_t ldsb = (size_t)(3 * W16_BUF + 64) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->reflect_adjoint) hipLaunchKernelGGL((conv_winograd16_kernel<true>), grid, dim3(512), ldsb, st, p);
+    else hipLaunchKernelGGL((conv_winograd16_kernel<false>), grid, dim3(512), ldsb, st, p);
+    C2S_CHECK_LAUNCH("conv3x3_winograd16");
+    return C2S_OK;
+}

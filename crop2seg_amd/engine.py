@@ -270,13 +270,20 @@ def _pack_bf16x3(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, co
 
 
 def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, cout: int, so: int, sc: int,
-                   taps: Sequence[int]) -> Tuple[Tensor, int]:
-    """U = G g Gt of every 3x3 filter, [16][cin][coutP] (cached per forward)."""
+                   taps: Sequence[int], wide: bool = False) -> Tuple[Tensor, int]:
+    """U = G g Gt of every 3x3 filter, [16][cin][coutP] (cached per forward); `wide` = the layout of the 8-wave kernel
+    (conv_winograd16.hip: [cout block][chunk][8 c][64 o][20])."""
     hit = ctx._packed.get(key)
     coutP = (cout + 63) // 64 * 64
     if hit is not None:
         return hit, coutP
     src_ptr = src.data_ptr() + 4 * src_off
+    if wide:
+        upk = torch.empty(lib().c2s_winograd16_packed_floats(cin, coutP), device=ctx.device, dtype=torch.float32)
+        check(lib().c2s_pack_weights_winograd16(src_ptr, upk.data_ptr(), cin, cout, coutP, so, sc, _tap_array(taps), _stream()),
+              "pack_weights_winograd16")
+        ctx._packed[key] = upk
+        return upk, coutP
     upk = ctx._planned(key, src_ptr)
     if upk is None:
         nfl = lib().c2s_winograd_packed_floats(cin, coutP)
@@ -322,6 +329,12 @@ CONV_MODE = _os.environ.get("C2S_CONV_MODE", "f32")
 assert CONV_MODE in ("f32", "bf16x3"), CONV_MODE
 # fp32 Winograd F(2x2,3x3) for the wide 3x3 layers (forward + data gradient); C2S_WINOGRAD=0 keeps the direct kernel.
 WINOGRAD = _os.environ.get("C2S_WINOGRAD", "1") != "0"
+# the 8-wave Winograd kernel with the output transform in registers (conv_winograd16.hip) for planes >= 32 wide
+WINO16 = _os.environ.get("C2S_WINO16", "0") != "0"
+
+
+def _wide_winograd(H: int, W: int) -> bool:
+    return WINO16 and W >= 32 and H >= 8
 
 # bench.py sets PROFILE = {"match": {field: value}, "events": []}: launches whose descriptor matches are bracketed
 # with HIP events on the launch stream (the stream the kernel runs on) for the live roofline measurement.
@@ -343,14 +356,15 @@ def _igemm(desc: ConvDesc, src0: Tensor, src1: Optional[Tensor], wpk: Tensor, bi
 
 
 def _winograd(desc: ConvDesc, src0: Tensor, src1: Optional[Tensor], upk: Tensor, bias: Optional[Tensor], out: Tensor,
-              valid: Optional[Tensor]) -> None:
+              valid: Optional[Tensor], wide: bool = False) -> None:
     prof = PROFILE
     timed = prof is not None and all(getattr(desc, k) == v for k, v in prof["match"].items())
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().c2s_conv3x3_winograd(C.byref(desc), src0.data_ptr(), _ptr(src1), upk.data_ptr(), _ptr(bias),
-                                     out.data_ptr(), _ptr(valid), _stream()), "conv3x3_winograd")
+    fn = lib().c2s_conv3x3_winograd16 if wide else lib().c2s_conv3x3_winograd
+    check(fn(C.byref(desc), src0.data_ptr(), _ptr(src1), upk.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(valid), _stream()),
+          "conv3x3_winograd")
     if timed:
         e1.record()
         prof["events"].append((e0, e1))
@@ -424,9 +438,10 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     KK = K * K
     out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
     if _use_winograd(K, S, pad, [C0, C1] if C1 else [C0], Cout, Hin, Win):
-        upk, CoutP = _pack_winograd(ctx, (wname, "fwd", "wino"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)))
+        wide = _wide_winograd(Hin, Win)
+        upk, CoutP = _pack_winograd(ctx, (wname, "fwd", "wino"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)), wide)
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
-        _winograd(d, s0, s1, upk, ctx.p[bname] if bname else None, out, valid)
+        _winograd(d, s0, s1, upk, ctx.p[bname] if bname else None, out, valid, wide)
     elif _use_bf16x3(K, S, pad, [C0, C1]):
         whi, wlo, CoutP = _pack_bf16x3(ctx, (wname, "fwd", "bx"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)))
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
@@ -464,10 +479,11 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             if S == 1:
                 taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
                 if _use_winograd(K, S, pad, [Cout], Cs, Hin, Win):
-                    upk, CP = _pack_winograd(ctx, (wname, "dgrad", "wino", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps)
+                    wide = _wide_winograd(Hin, Win)
+                    upk, CP = _pack_winograd(ctx, (wname, "dgrad", "wino", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps, wide)
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
                                   accf, radj)
-                    _winograd(dd, g, None, upk, None, gin, valid)
+                    _winograd(dd, g, None, upk, None, gin, valid, wide)
                 elif _use_bf16x3(K, S, pad, [Cout]):
                     whi, wlo, CP = _pack_bf16x3(ctx, (wname, "dgrad", "bx", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps)
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,

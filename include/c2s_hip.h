@@ -142,6 +142,19 @@ int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, const float*
                          const float* bias, float* out, const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The same Winograd F(2x2,3x3) convolution on v_mfma_f32_16x16x4_f32 with the output transform in registers (8-wave
+ * workgroups, 8 x 32 pixel tiles; conv_winograd16.hip) for planes at least 32 wide and 8 high.  Same descriptor and
+ * semantics as c2s_conv3x3_winograd; upk = c2s_pack_weights_winograd16 (c2s_winograd16_packed_floats(Cin, CoutP) floats,
+ * [cout block of 64][chunk of 8 input channels][8][64][20]).  c2s_conv3x3_winograd16_supported = the host-side predicate.
+ * ------------------------------------------------------------------------------------------------ */
+size_t c2s_winograd16_packed_floats(int cin, int coutP);
+int c2s_pack_weights_winograd16(const float* src, float* upk, int cin, int cout, int coutP, long stride_o, long stride_c,
+                                const int* host_tap_off, void* stream);
+int c2s_conv3x3_winograd16_supported(const c2s_conv_desc* d);
+int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
+                           const float* bias, float* out, const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Opt-in split-precision variant of the 3x3 stride-1 pad-1 convolution (forward and data gradient, same
  * descriptor as c2s_conv_igemm): every fp32 operand is split into two bf16 halves (hi + lo, 16 significant bits)
  * and each product evaluated with three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi) accumulating in fp32

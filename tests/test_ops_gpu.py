@@ -93,6 +93,54 @@ def test_conv2d_fwd_bwd(case):
     assert rel(ctx.g["w"], w.grad) < 5e-6
 
 
+WIDE_WINOGRAD_CASES = [
+    # N, C0, C1, Cout, H, W, mode
+    (2, 64, 0, 64, 128, 128, "reflect"),
+    (3, 64, 0, 64, 64, 64, "reflect"),          # padded frame 1
+    (2, 64, 0, 128, 32, 32, "reflect"),         # two blocks of output channels, one tile column
+    (1, 32, 0, 72, 12, 40, "reflect"),          # ragged: partial tiles in both directions, padded output channels
+    (2, 40, 0, 64, 8, 32, "zeros"),             # one tile per frame, zero padding, 5 chunks
+    (2, 32, 64, 64, 32, 64, "reflect"),         # two sources (the decoder's [up, skip])
+]
+
+
+@pytest.mark.parametrize("case", WIDE_WINOGRAD_CASES)
+def test_conv2d_wide_winograd(case):
+    """The 8-wave Winograd kernel (conv_winograd16.hip; C2S_WINO16) against the oracle: forward, data gradient (reflect
+    adjoint on the raw patches), and it must be the kernel that ran."""
+    E, L = _engine()
+    N, C0, C1, Cout, H, W, mode = case
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    valid = torch.ones(N, dtype=torch.int32)
+    if N >= 3:
+        valid[1] = 0
+    keep = valid.bool()
+    ref = O.conv2d(x[keep], w, b, 1, 1, mode)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({"w": w.detach(), "b": b.detach()})
+    xd = x.detach().cuda()
+    srcs = [xd] if C1 == 0 else [xd[:, :C0].contiguous(), xd[:, C0:].contiguous()]
+    old = E.WINO16
+    E.WINO16 = True
+    try:
+        assert E._use_winograd(3, 1, 1, [C0, C1] if C1 else [C0], Cout, H, W) and E._wide_winograd(H, W)
+        out = E.conv2d(ctx, srcs, "w", "b", 3, 1, 1, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZEROS, valid.cuda())
+        assert rel(out[keep.cuda()], ref) < 2e-6
+        gfull = torch.zeros(N, *ref.shape[1:])
+        gfull[keep] = gout
+        seed_backward(ctx, out, gfull)
+    finally:
+        E.WINO16 = old
+    gx = torch.cat([ctx.tape.grads[s.data_ptr()] for s in srcs], 1)
+    assert rel(gx[keep.cuda()], x.grad[keep]) < 5e-6
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 64, 4, 4), (2, 64, 32, 16, 16), (1, 32, 32, 64, 64)])
 def test_conv_transpose_fwd_bwd(shape):
     E, L = _engine()
