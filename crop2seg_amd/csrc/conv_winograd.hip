@@ -427,7 +427,7 @@ struct PackJob {
     float* dst;
     long so, sc;
     int cin, cout, coutP, ntaps;
-    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U
+    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U   2: Winograd U in the 8-wave kernel's layout
     int block_start;     // first block of this job
     int taps[16];
 };
@@ -461,6 +461,17 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
         t[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
         t[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
         t[3][q] = g[2][q];
+    }
+    if (jb.kind == 2) {          // the 8-wave kernel's layout (conv_winograd16.hip): [cout block][chunk][8 c][64 o][20], 16 used
+        float* wide = jb.dst + ((((size_t)(o >> 6) * nchunks + (c >> 3)) * WN_CK + (c & 7)) * 64 + (o & 63)) * 20;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wide[i * 4 + 0] = t[i][0];
+            wide[i * 4 + 1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+            wide[i * 4 + 2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+            wide[i * 4 + 3] = t[i][2];
+        }
+        return;
     }
     float* base = jb.dst + ((size_t)(o >> 6) * nchunks + (c >> 3)) * WN_USLAB + (c & 7) * 64 + (o & 63);
 #pragma unroll
@@ -499,10 +510,11 @@ extern "C" size_t c2s_pack_job_bytes(void) { return sizeof(PackJob); }
 // Fill one job record of a host-side table (the caller uploads the table once and reuses it every step)
 extern "C" int c2s_pack_job_fill(void* host_record, const float* src, float* dst, int cin, int cout, int coutP, int ntaps,
                                  long stride_o, long stride_c, int winograd, const int* host_tap_off, int block_start) {
-    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16, "pack_job_fill: bad args");
+    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16 && winograd >= 0 && winograd <= 2,
+                "pack_job_fill: bad args");
     PackJob* j = reinterpret_cast<PackJob*>(host_record);
     j->src = src; j->dst = dst; j->so = stride_o; j->sc = stride_c;
-    j->cin = cin; j->cout = cout; j->coutP = coutP; j->ntaps = ntaps; j->kind = winograd ? 1 : 0; j->block_start = block_start;
+    j->cin = cin; j->cout = cout; j->coutP = coutP; j->ntaps = ntaps; j->kind = winograd; j->block_start = block_start;
     for (int i = 0; i < 16; ++i) j->taps[i] = i < ntaps ? host_tap_off[i] : 0;
     return C2S_OK;
 }

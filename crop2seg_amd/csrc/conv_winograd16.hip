@@ -54,10 +54,14 @@ constexpr int W16_PLANE = W16_RR * W16_RC;          // 340
 constexpr int W16_XP = 352;                         // LDS pitch per channel (= 32 mod 64 banks: the four k groups of a wave do not collide)
 constexpr int W16_MAXE = 6;                         // raw-tile LDS-DMA pieces per thread (one float each)
 constexpr int W16_XS = W16_MAXE * 512;              // 3,072 floats: 8 x 352 and a zero-filled tail
-constexpr int W16_BUF = W16_USLAB + W16_XS;         // 13,312 floats = 52 KB; three buffers = 156 KB
+constexpr int W16_UHALF = W16_USLAB / 2;            // a k-step's half slab (4 channels): 20 KB; ring of five
+constexpr int W16_URING = 5 * W16_UHALF;            // 100 KB
+constexpr int W16_XSLOTS = 4;                       // raw-tile ring: 48 KB
+constexpr int W16_LDS_FLOATS = W16_URING + W16_XSLOTS * W16_XS + 64;     // + the bias of the 64 channels: 151,808 B (+ frame flag bits)
 constexpr int W16_WPT = W16_USLAB / 4 / 512;        // 5 LDS-DMA pieces per thread
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // tools/wino16_diag.py builds diagnostic copies with one part of the kernel removed (results are then wrong by design):
 //   1 = no MFMA, 2 = no staging after the first two chunks, 3 = no output stores, 4 = no LDS operand reads in the K loop,
 //   5 = 2 and 4 together (MFMA + transform + epilogue only), 6 = 5 without the barrier per chunk, 7 = 5 without the transforms,
@@ -67,6 +71,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 #define C2S_AS1 __attribute__((address_space(1)))
 #define C2S_AS3 __attribute__((address_space(3)))
+
+// a - b - c on channel pairs as two v_pk_add_f32 with negated second operands (the compiler leaves vector subtractions
+// scalar).  Only used after the s_nop block that follows the K loop: asm operands are invisible to the MFMA -> VALU hazard
+// recogniser.
+__device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %0, %0, %3 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <bool ADJ>
 __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p) {
@@ -81,8 +95,24 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     const int ntotal = p.N * p.tiles;
     const int K = p.nchunks;
 
+    // frame flags as a bit mask in LDS (behind the rings and the bias): the tile walk must not touch the vector-memory
+    // counter, which orders the LDS-DMA requests in flight
+    unsigned* lvalid = reinterpret_cast<unsigned*>(lds + W16_URING + W16_XSLOTS * W16_XS + 64);
+    for (int wi = tid; wi < (p.N + 31) / 32; wi += 512) {
+        unsigned m = 0;
+        for (int b = 0; b < 32; ++b) {
+            const int f = wi * 32 + b;
+            if (f < p.N && (p.valid == nullptr || p.valid[f] != 0)) m |= 1u << b;
+        }
+        lvalid[wi] = m;
+    }
+    __syncthreads();
     auto next_valid = [&](int tt) {
-        while (tt < ntotal && p.valid != nullptr && p.valid[tt / p.tiles] == 0) tt += gridDim.x;
+        while (tt < ntotal) {
+            const int f = tt / p.tiles;
+            if ((lvalid[f >> 5] >> (f & 31)) & 1u) break;
+            tt += gridDim.x;
+        }
         return tt;
     };
     auto tile_origin = [&](int tt, int& n, int& oy0, int& ox0) {
@@ -95,12 +125,12 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     // ---- the staging side runs two chunks ahead of the MFMAs, across tile boundaries: its own tile state
     int goff[W16_MAXE];
     int diag_staged = 0;
-    int scand = 0, cflag = 1;                          // the tile after the staging tile and its frame's flag (fetched a tile ahead)
     __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src0, 0, 0, 0x00020000), r1 = r0;
     auto begin_staging = [&](int tt) {
         int n, oy0, ox0;
         tile_origin(tt, n, oy0, ox0);
         if (C2S_W16_DIAG == 10) n = 0;
+        if (C2S_W16_DIAG >= 100) n %= (C2S_W16_DIAG - 100);       // 100 + F: raw tiles from the first F frames only
 #pragma unroll
         for (int i = 0; i < W16_MAXE; ++i) {              // LDS float e = tid + 512 i of the raw tile: (channel, row, col)
             const int e = tid + i * 512;
@@ -110,10 +140,8 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
                             (reflect ? (gy <= p.H && gx <= p.W) : (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W));
             gy = reflect_idx(gy, p.H);                    // (identity inside the plane)
             gx = reflect_idx(gx, p.W);
-            goff[i] = ok ? ((c * HW + gy * p.W + gx) * 4) : -1;
+            goff[i] = ok ? ((c * HW + gy * p.W + gx) * 4) : 0x7FFF0000;     // (out of range whatever the channel offset)
         }
-        scand = tt + gridDim.x;
-        cflag = (p.valid != nullptr && scand < ntotal) ? p.valid[scand / p.tiles] : 1;    // used K chunks from now
         const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
         const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
         r0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HW * 4, 0x00020000);
@@ -121,26 +149,32 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     };
     // both operands by LDS-DMA.  U: 40 KB per chunk, packed lane-linear.  Raw tile: one float per lane and piece, lane-linear in
     // LDS, gathered (reflected) global addresses; out-of-range offsets (-1: zero padding, tile overhang, the tail) read as 0
-    const float* ublock = p.upk + (size_t)blockIdx.y * K * W16_USLAB + tid * 4;
-    auto stage_u = [&](int k, int buf) {
-        float* Wd = lds + buf * W16_BUF + tid * 4;
-        const float* g = ublock + (size_t)k * W16_USLAB;
+    // U chunk k -> half slabs h0 and h0 + 1 (mod 5) of the ring; the 40 KB are contiguous in global memory, piece 2 straddles
+    // the halves at a wave boundary (waves 0-3 | 4-7)
+    // (addresses of the requests: LDS destinations and channel offsets are wave-uniform and stay in scalar registers -- a
+    // VALU instruction costs the SIMD ~8 cycles of MFMA issue, see the header)
+    auto stage_u = [&](int k, int h0) {
+        if (C2S_W16_DIAG == 9 && diag_staged >= 2) return;
+        const int h1 = h0 == 4 ? 0 : h0 + 1;
+        const C2S_AS1 char* g = (const C2S_AS1 char*)p.upk + ((size_t)blockIdx.y * K + k) * (W16_USLAB * 4);
+        float* d0 = lds + h0 * W16_UHALF + w * 256;
+        float* d1 = lds + h1 * W16_UHALF + w * 256 - W16_UHALF;
 #pragma unroll
-        for (int i = 0; i < W16_WPT; ++i)
-            if (C2S_W16_DIAG != 9 || diag_staged < 2)
-                __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 2048), (C2S_AS3 void*)(Wd + i * 2048), 16, 0, 0);
+        for (int i = 0; i < W16_WPT; ++i) {
+            float* dst = (i < 2 || (i == 2 && w < 4)) ? d0 : d1;
+            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 8192 + (unsigned)(tid * 16)), (C2S_AS3 void*)(dst + i * 2048), 16, 0, 0);
+        }
     };
-    auto stage_raw = [&](int k, int buf) {
+    auto stage_raw = [&](int k, int slot) {
         if (C2S_W16_DIAG == 8 && diag_staged >= 2) return;
         const int cb_ = k * W16_CK;
         const bool first = cb_ < p.C0;
-        const int chan0 = (first ? cb_ : cb_ - p.C0) * HW * 4;
-        float* Xd = lds + buf * W16_BUF + W16_USLAB + (tid & ~63);
+        const int chan0 = (first ? cb_ : cb_ - p.C0) * HW * 4;            // scalar offset of the request
+        float* Xd = lds + W16_URING + slot * W16_XS + w * 64;
 #pragma unroll
         for (int i = 0; i < W16_MAXE; ++i) {
-            const int off = goff[i] >= 0 ? goff[i] + chan0 : -1;
-            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (C2S_AS3 void*)(Xd + i * 512), 4, off, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (C2S_AS3 void*)(Xd + i * 512), 4, off, 0, 0, 0);
+            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (C2S_AS3 void*)(Xd + i * 512), 4, goff[i], chan0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (C2S_AS3 void*)(Xd + i * 512), 4, goff[i], chan0, 0, 0);
         }
     };
     // XCD-aware start (as conv_winograd.hip): each XCD walks a contiguous eighth of the tiles in flight
@@ -149,40 +183,48 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     if (tile >= ntotal) return;
     int stile = tile, sk = 0;                          // next chunk to stage: chunk sk of tile stile (stile >= ntotal: none left)
     begin_staging(stile);
-    // the two halves of one chunk's requests (uniform across the workgroup): the raw tile (HBM latency) first, U (L2) later
+    // Requests (uniform across the workgroup).  The raw tile comes from HBM and is requested THREE chunks ahead of the MFMAs
+    // (tools/wino16_diag.py: with two, ~130 us of the 64->64 @128^2 launch were waits for it), U (L2 hits) two ahead.  The U
+    // chunk to request next is the one the raw side requested a step earlier: (u_ok, u_k).
     const bool diag_stage = (C2S_W16_DIAG != 2 && C2S_W16_DIAG < 5);
-    auto stage_next_raw = [&](int buf) {
-        if (stile < ntotal && (diag_stage || diag_staged < 2)) stage_raw(sk, buf);
+    bool u_ok = false, young_raw = false;
+    int u_k = 0;
+    auto stage_next_u = [&](int h0) {
+        if (u_ok && (diag_stage || diag_staged < 2)) stage_u(u_k, h0);
     };
-    auto stage_next_u = [&](int buf) {
-        if (stile >= ntotal) return;
-        if (diag_stage || diag_staged < 2) stage_u(sk, buf);
+    auto stage_next_raw = [&](int slot) {
+        u_ok = stile < ntotal;
+        u_k = sk;
+        young_raw = u_ok;
+        if (!u_ok) return;
+        if (diag_stage || diag_staged < 2) stage_raw(sk, slot);
         ++diag_staged;
-        if (++sk == K) {                               // once per multiplied tile (K >= 3), at its chunk K - 3
+        if (++sk == K) {                               // once per multiplied tile (K >= 4), at its chunk K - 4
             sk = 0;
-            stile = __builtin_amdgcn_readfirstlane(cflag) != 0 ? scand : next_valid(scand + gridDim.x);
+            stile = next_valid(stile + gridDim.x);
             if (stile < ntotal) begin_staging(stile);
         }
     };
-    int cur = 0;                                       // buffer of the chunk being multiplied (three buffers in rotation)
+    int u0 = 0, rc = 0;                                // ring positions of the chunk being multiplied: U half slab of k-step 0, raw slot
     stage_next_raw(0); stage_next_u(0);
-    stage_next_raw(1); stage_next_u(1);
+    stage_next_raw(1); stage_next_u(2);
+    stage_next_raw(2);
 
     // LDS offsets of this lane's operands inside a buffer
-    const int aoff = (kq * 64 + 32 * ch + t) * W16_UP;                          // + s * 4 * 64 * UP + mt * 16 * UP
-    const int boff = W16_USLAB + kq * W16_XP + (2 * brow) * W16_RC + 2 * t;     // + s * 4 * XP + r * RC
-    auto load_a = [&](const float* ab, int s, int mt, float (&a)[16]) {
-        if ((C2S_W16_DIAG >= 4) && ab != lds + aoff) return;
+    const int aoff = (kq * 64 + 32 * ch + t) * W16_UP;                          // in a half slab; + mt * 16 * UP
+    const int boff = W16_URING + kq * W16_XP + (2 * brow) * W16_RC + 2 * t;     // in a raw slot; + s * 4 * XP + r * RC
+    auto load_a = [&](const float* ab, int mt, float (&a)[16]) {                 // ab: this lane's row of a half slab
+        if (C2S_W16_DIAG >= 4 && C2S_W16_DIAG <= 7 && ab != lds + aoff) return;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ab + (s * 4 * 64 + mt * 16) * W16_UP + 4 * q4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ab + mt * 16 * W16_UP + 4 * q4);
             a[4 * q4] = v[0]; a[4 * q4 + 1] = v[1]; a[4 * q4 + 2] = v[2]; a[4 * q4 + 3] = v[3];
         }
     };
     int boff0 = boff, boff1 = boff + 4 * W16_XP;       // (the two k-steps; opaque, so that the row offsets stay ds_read2 immediates)
     asm volatile("" : "+v"(boff0), "+v"(boff1));
     auto load_d = [&](const float* bufp, int s, f32x2 (&dl)[4], f32x2 (&dh)[4]) {     // patch rows as (cols 0,1), (cols 2,3)
-        if ((C2S_W16_DIAG >= 4) && bufp != lds) return;
+        if (C2S_W16_DIAG >= 4 && C2S_W16_DIAG <= 7 && bufp != lds) return;
         const float* bb = bufp + (s ? boff1 : boff0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -244,13 +286,21 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
         }
     };
     f32x4 acc[16][2];
-    auto mma = [&](const float (&a)[16], const float (&V)[16], int mt) {
+    float* lbias = lds + W16_URING + W16_XSLOTS * W16_XS;      // the 64 channels' bias (behind the rings)
+    // first = the first k-step of a tile: the accumulators start at 0 (an inline constant: no 128 v_mov per tile), those of
+    // point (1,1) at the bias: At e11 A = [[1,1],[1,1]]
+    auto mma = [&](const float (&a)[16], const float (&V)[16], int mt, bool first) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
 #if C2S_W16_DIAG == 1
             asm volatile("" ::"v"(a[q]), "v"(V[q]));
 #else
-            acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], acc[q][mt], 0, 0, 0);
+            if (first) {
+                const f32x4 c0 = q == 5 ? *reinterpret_cast<const f32x4*>(lbias + 32 * ch + 16 * mt + 4 * kq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], c0, 0, 0, 0);
+            } else {
+                acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], acc[q][mt], 0, 0, 0);
+            }
 #endif
         }
     };
@@ -262,11 +312,9 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     float a0[16], a1[16], V[16];
     f32x2 dl[4], dh[4], el[4], eh[4];
     const int cof = co0 + 32 * ch + 4 * kq;            // this lane's output channels: cof + 16 mt + r (D rows 4 kq + r)
-    // bias: At e11 A = [[1,1],[1,1]], so a tile's accumulators of point (1,1) start at the bias (64 floats behind the buffers)
-    float* lbias = lds + 3 * W16_BUF;
     if (tid < 64) lbias[tid] = (p.bias != nullptr && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
-    __syncthreads();                                  // (drains the first chunk's LDS-DMA: vmcnt(0))
-    load_a(lds + aoff, 0, 0, a0);
+    __syncthreads();                                  // (drains the first requests: vmcnt(0))
+    load_a(lds + aoff, 0, a0);
     load_d(lds, 0, dl, dh);
     while (true) {
         int n, oy0, ox0;
@@ -280,81 +328,94 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
             rowfold = gby == 0 || gby == lasty;
             colfold = ox0 == 0 || (ox0 >> 1) + W16_BC > lastx;
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[q][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[5][mt] = *reinterpret_cast<const f32x4*>(lbias + 32 * ch + 16 * mt + 4 * kq);
-        for (int k = 0; k < K; ++k) {
-            const int nb = cur == 2 ? 0 : cur + 1, fb = nb == 2 ? 0 : nb + 1;
-            const float* ab = lds + cur * W16_BUF + aoff;
-            const float* bb = lds + cur * W16_BUF;
-            load_a(ab, 0, 1, a1);
+        auto chunk = [&](bool first) {
+            const int u1 = u0 == 4 ? 0 : u0 + 1, u2 = u1 == 4 ? 0 : u1 + 1;    // this chunk's second half slab; the next chunk's first
+            const float* xb = lds + rc * W16_XS;
+            load_a(lds + u0 * W16_UHALF + aoff, 1, a1);
             __builtin_amdgcn_sched_barrier(0);
-            if (C2S_W16_DIAG != 7 || k == 0) transform(dl, dh, V);
+            if (C2S_W16_DIAG != 7 || first) transform(dl, dh, V);
             __builtin_amdgcn_sched_barrier(0);
-            load_d(bb, 1, el, eh);                     // (after the transform: its temporaries are dead)
+            load_d(xb, 1, el, eh);                     // (after the transform: its temporaries are dead)
             __builtin_amdgcn_sched_barrier(0);
-            mma(a0, V, 0);
+            mma(a0, V, 0, first);
             __builtin_amdgcn_sched_barrier(0);
-            load_a(ab, 1, 0, a0);
+            load_a(lds + u1 * W16_UHALF + aoff, 0, a0);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a1, V, 1);
+            mma(a1, V, 1, first);
             __builtin_amdgcn_sched_barrier(0);
-            if (C2S_W16_DIAG != 6) __syncthreads();
-            stage_next_raw(fb);
-            load_a(ab, 1, 1, a1);
+            // everyone's requests for the NEXT chunk have landed (U: issued one chunk ago; raw: two); the six youngest (the
+            // raw pieces of the chunk after next) may stay in flight -- loads complete in order
+            if (C2S_W16_DIAG != 6) {
+                if (young_raw) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+                else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stage_next_u(u0 == 0 ? 4 : u0 - 1);        // chunk after next: half slabs u0 + 4, u0 + 5 = u0 (mod 5)
+            stage_next_raw((rc + 3) & 3);
+            load_a(lds + u1 * W16_UHALF + aoff, 1, a1);
             __builtin_amdgcn_sched_barrier(0);
             if (C2S_W16_DIAG != 7) transform(el, eh, V);
-            mma(a0, V, 0);
+            mma(a0, V, 0, false);
             __builtin_amdgcn_sched_barrier(0);
-            stage_next_u(fb);
-            load_a(lds + nb * W16_BUF + aoff, 0, 0, a0);       // (after the last chunk of the last tile: stale, unused)
-            load_d(lds + nb * W16_BUF, 0, dl, dh);
+            load_a(lds + u2 * W16_UHALF + aoff, 0, a0);                  // (after the last chunk of the last tile: stale, unused)
+            load_d(lds + ((rc + 1) & 3) * W16_XS, 0, dl, dh);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a1, V, 1);
+            mma(a1, V, 1, false);
             __builtin_amdgcn_sched_barrier(0);
-            cur = nb;
-        }
-        // ---- epilogue: At M A per (channel, block) in registers; lane (t, kq): channels cof + 16 mt + r, block (brow, t)
+            u0 = u2;
+            rc = (rc + 1) & 3;
+        };
+        chunk(true);
+        for (int k = 1; k < K; ++k) chunk(false);
+        asm volatile("s_nop 7\n\ts_nop 7");             // the last MFMA results are readable by the asm adds of the epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: At M A per (channel, block) in registers, on channel PAIRS (the accumulator's adjacent registers:
+        // v_pk_add_f32), transposed to (column 0, column 1) for one 8-byte store per output row; lane (t, kq): channels
+        // cof + 16 mt + r, block (brow, t).  Buffer stores: the channel offset is scalar, an out-of-plane lane or a padded
+        // channel is an out-of-range offset -- no address arithmetic or lane masks in the vector ALU
         const int oy = oy0 + 2 * brow, ox = ox0 + 2 * t;
-        float* on = p.out + (size_t)n * p.Cout * HW;
-        const int H_ = p.H, W_ = p.W;
-        const bool in0 = ox < W_ && oy < H_, in1 = ox < W_ && oy + 1 < H_;
+        const __amdgpu_buffer_rsrc_t ro =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)n * p.Cout * HW), 0, p.Cout * HW * 4, 0x00020000);
+        const bool in0 = ox < p.W && oy < p.H && C2S_W16_DIAG != 3, in1 = in0 && oy + 1 < p.H;
+        const int vo0 = in0 ? (cof * HW + oy * p.W + ox) * 4 : 0x7FFF0000;
+        const int vo1 = in1 ? vo0 + p.W * 4 : 0x7FFF0000;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            f32x2 y[4][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float P[4][2];
+            for (int h = 0; h < 2; ++h) {
+                f32x2 P0[4], P1[4];
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
-                    const float m0 = acc[4 * xi][mt][r], m1 = acc[4 * xi + 1][mt][r], m2 = acc[4 * xi + 2][mt][r], m3 = acc[4 * xi + 3][mt][r];
-                    P[xi][0] = m0 + m1 + m2;
-                    P[xi][1] = m1 - m2 - m3;
+                    f32x2 m[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = (f32x2){acc[4 * xi + j][mt][2 * h], acc[4 * xi + j][mt][2 * h + 1]};
+                    P0[xi] = m[0] + m[1] + m[2];
+                    P1[xi] = sub2(m[1], m[2], m[3]);
                 }
-                y[r][0] = (f32x2){P[0][0] + P[1][0] + P[2][0], P[0][1] + P[1][1] + P[2][1]};
-                y[r][1] = (f32x2){P[1][0] - P[2][0] - P[3][0], P[1][1] - P[2][1] - P[3][1]};
-            }
-            const int cq = cof + 16 * mt;
-            float* row0 = on + (size_t)cq * HW + (size_t)oy * W_ + ox;
-            if (p.accumulate) {                        // all eight reads in flight before the first add
-                f32x2 o[4][2];
+                const f32x2 Y00 = P0[0] + P0[1] + P0[2], Y01 = P1[0] + P1[1] + P1[2];
+                const f32x2 Y10 = sub2(P0[1], P0[2], P0[3]), Y11 = sub2(P1[1], P1[2], P1[3]);
+                f32x2 y[2][2] = {{(f32x2){Y00[0], Y01[0]}, (f32x2){Y10[0], Y11[0]}},        // [channel of the pair][output row]
+                                 {(f32x2){Y00[1], Y01[1]}, (f32x2){Y10[1], Y11[1]}}};
+                const int so = (16 * mt + 2 * h) * HW * 4;
+                if (p.accumulate) {                    // the four reads in flight before the first add
+                    u32x2 o[2][2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool okc = cq + r < p.Cout;
-                    o[r][0] = okc && in0 ? *reinterpret_cast<const f32x2*>(row0 + (size_t)r * HW) : (f32x2){0.f, 0.f};
-                    o[r][1] = okc && in1 ? *reinterpret_cast<const f32x2*>(row0 + (size_t)r * HW + W_) : (f32x2){0.f, 0.f};
+                    for (int j = 0; j < 2; ++j) {
+                        o[j][0] = __builtin_amdgcn_raw_buffer_load_b64(ro, vo0, so + j * HW * 4, 0);
+                        o[j][1] = __builtin_amdgcn_raw_buffer_load_b64(ro, vo1, so + j * HW * 4, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        y[j][0] += __builtin_bit_cast(f32x2, o[j][0]);
+                        y[j][1] += __builtin_bit_cast(f32x2, o[j][1]);
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { y[r][0] += o[r][0]; y[r][1] += o[r][1]; }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool okc = cq + r < p.Cout && (C2S_W16_DIAG != 3 || oy < 0);
-                if (okc && in0) *reinterpret_cast<f32x2*>(row0 + (size_t)r * HW) = y[r][0];
-                if (okc && in1) *reinterpret_cast<f32x2*>(row0 + (size_t)r * HW + W_) = y[r][1];
+                for (int j = 0; j < 2; ++j) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y[j][0]), ro, vo0, so + j * HW * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y[j][1]), ro, vo1, so + j * HW * 4, 0);
+                }
             }
         }
         if (stile >= ntotal) break;
@@ -424,18 +485,19 @@ extern "C" int c2s_pack_weights_winograd16(const float* src, float* upk, int cin
 
 extern "C" int c2s_conv3x3_winograd16_supported(const c2s_conv_desc* d) {
     return d && d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Hin % 2 == 0 && d->Win % 2 == 0 &&
-           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 2 * W16_CK && (d->C1 == 0 || d->C0 % W16_CK == 0);
+           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 3 * W16_CK && (d->C1 == 0 || d->C0 % W16_CK == 0);
 }
 
 extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
                                       const float* bias, float* out, const int* valid, void* stream) {
     C2S_REQUIRE(d && src0 && upk && out, "conv3x3_winograd16: null pointer");
     C2S_REQUIRE(c2s_conv3x3_winograd16_supported(d), "conv3x3_winograd16: 3x3 stride 1 pad 1, even planes at least 32 wide and 8 high, CoutP %% 64");
-    C2S_REQUIRE(d->N > 0 && d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0 || src1), "conv3x3_winograd16: bad channels");
+    C2S_REQUIRE(d->N > 0 && d->N <= 65536 && d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0 || src1), "conv3x3_winograd16: bad channels / more than 65536 frames");
     C2S_REQUIRE(d->Hout == d->Hin && d->Wout == d->Win && d->OutH == d->Hout && d->OutW == d->Wout && d->osy == 1 &&
                 d->osx == 1 && d->ooy == 0 && d->oox == 0, "conv3x3_winograd16: dense same-size output only");
     C2S_REQUIRE(d->CoutP >= d->Cout && d->Cout > 0, "conv3x3_winograd16: bad CoutP");
-    C2S_REQUIRE((long)(d->C0 > d->C1 ? d->C0 : d->C1) * d->Hin * d->Win * 4 < (1L << 31), "conv3x3_winograd16: frame too large");
+    C2S_REQUIRE((long)(d->C0 > d->C1 ? d->C0 : d->C1) * d->Hin * d->Win * 4 < (1L << 31) &&
+                (long)d->CoutP * d->Hin * d->Win * 4 < 0x7FFF0000L, "conv3x3_winograd16: frame too large");
     if (d->reflect_adjoint) C2S_REQUIRE(d->pad_mode == C2S_PAD_ZEROS, "conv3x3_winograd16: the reflect adjoint is a zero-padded launch");
     Wino16Params p;
     p.src0 = src0; p.src1 = src1; p.upk = upk; p.bias = bias; p.out = out; p.valid = valid;
@@ -451,7 +513,7 @@ extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0,
     long gx = ((long)cus + cblocks - 1) / cblocks;  // persistent: one 8-wave workgroup per CU
     if (gx > ntotal) gx = ntotal;
     dim3 grid((unsigned)gx, cblocks, 1);
-    const size_t ldsb = (size_t)(3 * W16_BUF + 64) * sizeof(float);
+    const size_t ldsb = (size_t)(W16_LDS_FLOATS + (d->N + 31) / 32) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (d->reflect_adjoint) hipLaunchKernelGGL((conv_winograd16_kernel<true>), grid, dim3(512), ldsb, st, p);
     else hipLaunchKernelGGL((conv_winograd16_kernel<false>), grid, dim3(512), ldsb, st, p);

@@ -278,19 +278,13 @@ def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, 
     if hit is not None:
         return hit, coutP
     src_ptr = src.data_ptr() + 4 * src_off
-    if wide:
-        upk = torch.empty(lib().c2s_winograd16_packed_floats(cin, coutP), device=ctx.device, dtype=torch.float32)
-        check(lib().c2s_pack_weights_winograd16(src_ptr, upk.data_ptr(), cin, cout, coutP, so, sc, _tap_array(taps), _stream()),
-              "pack_weights_winograd16")
-        ctx._packed[key] = upk
-        return upk, coutP
     upk = ctx._planned(key, src_ptr)
     if upk is None:
-        nfl = lib().c2s_winograd_packed_floats(cin, coutP)
+        nfl = (lib().c2s_winograd16_packed_floats if wide else lib().c2s_winograd_packed_floats)(cin, coutP)
         upk = torch.empty(nfl, device=ctx.device, dtype=torch.float32)
-        check(lib().c2s_pack_weights_winograd(src_ptr, upk.data_ptr(), cin, cout, coutP, so, sc, _tap_array(taps), _stream()),
-              "pack_weights_winograd")
-        ctx.ws.pack_record[key] = (src_ptr, cin, cout, coutP, 9, so, sc, 1, tuple(taps), nfl)
+        fn = lib().c2s_pack_weights_winograd16 if wide else lib().c2s_pack_weights_winograd
+        check(fn(src_ptr, upk.data_ptr(), cin, cout, coutP, so, sc, _tap_array(taps), _stream()), "pack_weights_winograd")
+        ctx.ws.pack_record[key] = (src_ptr, cin, cout, coutP, 9, so, sc, 2 if wide else 1, tuple(taps), nfl)
     ctx._packed[key] = upk
     return upk, coutP
 
@@ -329,12 +323,14 @@ CONV_MODE = _os.environ.get("C2S_CONV_MODE", "f32")
 assert CONV_MODE in ("f32", "bf16x3"), CONV_MODE
 # fp32 Winograd F(2x2,3x3) for the wide 3x3 layers (forward + data gradient); C2S_WINOGRAD=0 keeps the direct kernel.
 WINOGRAD = _os.environ.get("C2S_WINOGRAD", "1") != "0"
-# the 8-wave Winograd kernel with the output transform in registers (conv_winograd16.hip) for planes >= 32 wide
-WINO16 = _os.environ.get("C2S_WINO16", "0") != "0"
+# the 8-wave Winograd kernel with the output transform in registers (conv_winograd16.hip) for planes >= 32 wide;
+# C2S_WINO16=0 keeps the 4-wave kernel (conv_winograd.hip) everywhere
+WINO16 = _os.environ.get("C2S_WINO16", "1") != "0"
 
 
-def _wide_winograd(H: int, W: int) -> bool:
-    return WINO16 and W >= 32 and H >= 8
+def _wide_winograd(H: int, W: int, cin: int) -> bool:
+    """c2s_conv3x3_winograd16_supported on top of _use_winograd: planes >= 32 wide, at least four chunks of 8 channels."""
+    return WINO16 and W >= 32 and H >= 8 and cin > 24
 
 # bench.py sets PROFILE = {"match": {field: value}, "events": []}: launches whose descriptor matches are bracketed
 # with HIP events on the launch stream (the stream the kernel runs on) for the live roofline measurement.
@@ -438,7 +434,7 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     KK = K * K
     out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
     if _use_winograd(K, S, pad, [C0, C1] if C1 else [C0], Cout, Hin, Win):
-        wide = _wide_winograd(Hin, Win)
+        wide = _wide_winograd(Hin, Win, Cin)
         upk, CoutP = _pack_winograd(ctx, (wname, "fwd", "wino"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)), wide)
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
         _winograd(d, s0, s1, upk, ctx.p[bname] if bname else None, out, valid, wide)
@@ -479,7 +475,7 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             if S == 1:
                 taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
                 if _use_winograd(K, S, pad, [Cout], Cs, Hin, Win):
-                    wide = _wide_winograd(Hin, Win)
+                    wide = _wide_winograd(Hin, Win, Cout)
                     upk, CP = _pack_winograd(ctx, (wname, "dgrad", "wino", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps, wide)
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
                                   accf, radj)

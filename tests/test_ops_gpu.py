@@ -128,7 +128,7 @@ def test_conv2d_wide_winograd(case):
     old = E.WINO16
     E.WINO16 = True
     try:
-        assert E._use_winograd(3, 1, 1, [C0, C1] if C1 else [C0], Cout, H, W) and E._wide_winograd(H, W)
+        assert E._use_winograd(3, 1, 1, [C0, C1] if C1 else [C0], Cout, H, W) and E._wide_winograd(H, W, Cin)
         out = E.conv2d(ctx, srcs, "w", "b", 3, 1, 1, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZEROS, valid.cuda())
         assert rel(out[keep.cuda()], ref) < 2e-6
         gfull = torch.zeros(N, *ref.shape[1:])

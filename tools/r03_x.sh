@@ -1,10 +1,9 @@
 #!/bin/bash
-# scratch: wide Winograd kernel A/B
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "wide_winograd" > gpurun_out/w16_test.log 2>&1
-echo "test rc=$?" >> gpurun_out/w16_test.log
-tail -5 gpurun_out/w16_test.log
-grep -q "test rc=0" gpurun_out/w16_test.log || exit 1
-timeout -k 10 300 python tools/wino16_diag.py 0 1 2 > gpurun_out/w16_diag.log 2>&1
-cat gpurun_out/w16_diag.log
+for i in 1 2 3; do
+C2S_WINO16=0 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('wino16=0', d['ms_per_step'], d['value'])" && \
+C2S_WINO16=1 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('wino16=1', d['ms_per_step'], d['value'])" || exit 1
+done
+C2S_WINO16=0 timeout -k 10 300 python bench.py --model timeunet --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('timeunet wino16=0', d['ms_per_step'], d['value'])"
+C2S_WINO16=1 timeout -k 10 300 python bench.py --model timeunet --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('timeunet wino16=1', d['ms_per_step'], d['value'])"

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def child(libpath):
+def child(libpath, shapes=((128, 64, 128),)):
     import ctypes as C
     import torch
     from crop2seg_amd import _lib
@@ -19,26 +19,38 @@ def child(libpath):
     L = _lib
     lib = E.lib()
     dev = torch.device("cuda")
-    N, Cc, H = 128, 64, 128
+    for N, Cc, H in shapes:
+        child_shape(lib, L, E, C, torch, dev, N, Cc, H)
+
+
+def child_shape(lib, L, E, C, torch, dev, N, Cc, H):
     w = torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05
     b = torch.randn(Cc, device=dev)
     x = torch.randn(N, Cc, H, H, device=dev)
     out = torch.empty_like(x)
-    for adj in (0, 1):
-        upk = torch.empty(lib.c2s_winograd16_packed_floats(Cc, 64), device=dev)
-        taps = (C.c_int * 9)(*range(9))
-        E.check(lib.c2s_pack_weights_winograd16(w.data_ptr(), upk.data_ptr(), Cc, Cc, 64, Cc * 9, 9, taps, None), "pack")
-        d = L.ConvDesc(N, Cc, 0, H, H, Cc, 64, H, H, H, H, 3, 3, 1, 1, 1, L.PAD_ZEROS if adj else L.PAD_REFLECT, 1, 1, 0, 0, 0, adj)
-        ts = []
-        for i in range(13):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            E.check(lib.c2s_conv3x3_winograd16(C.byref(d), x.data_ptr(), None, upk.data_ptr(), None if adj else b.data_ptr(),
-                                               out.data_ptr(), None, None), "conv")
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        print(f"   {'data gradient' if adj else 'forward      '}: min {min(ts[1:]) * 1e3:7.1f} us   median {sorted(ts[1:])[6] * 1e3:7.1f} us", flush=True)
+    CP = (Cc + 63) // 64 * 64
+    taps = (C.c_int * 9)(*range(9))
+    for wide in (1, 0):
+        for adj in (0, 1):
+            if wide:
+                upk = torch.empty(lib.c2s_winograd16_packed_floats(Cc, CP), device=dev)
+                E.check(lib.c2s_pack_weights_winograd16(w.data_ptr(), upk.data_ptr(), Cc, Cc, CP, Cc * 9, 9, taps, None), "pack")
+                fn = lib.c2s_conv3x3_winograd16
+            else:
+                upk = torch.empty(lib.c2s_winograd_packed_floats(Cc, CP), device=dev)
+                E.check(lib.c2s_pack_weights_winograd(w.data_ptr(), upk.data_ptr(), Cc, Cc, CP, Cc * 9, 9, taps, None), "pack")
+                fn = lib.c2s_conv3x3_winograd
+            d = L.ConvDesc(N, Cc, 0, H, H, Cc, CP, H, H, H, H, 3, 3, 1, 1, 1, L.PAD_ZEROS if adj else L.PAD_REFLECT, 1, 1, 0, 0, 0, adj)
+            ts = []
+            for i in range(13):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                E.check(fn(C.byref(d), x.data_ptr(), None, upk.data_ptr(), None if adj else b.data_ptr(), out.data_ptr(), None, None), "conv")
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            print(f"   N={N} {Cc}->{Cc} @{H}  {'8-wave' if wide else '4-wave'} {'data gradient' if adj else 'forward      '}: "
+                  f"min {min(ts[1:]) * 1e3:7.1f} us   median {sorted(ts[1:])[6] * 1e3:7.1f} us", flush=True)
 
 
 def build_variant(v):
@@ -55,22 +67,24 @@ def build_variant(v):
     return out
 
 
-NAMES = {0: "as built", 1: "no MFMA", 2: "no staging after the first two chunks", 3: "no output stores",
+NAMES = {102: "raw tiles from frames 0-1 (8 MB)", 108: "raw tiles from frames 0-7 (32 MB)", 132: "raw tiles from frames 0-31 (128 MB)",
+         0: "as built", 1: "no MFMA", 2: "no staging after the first two chunks", 3: "no output stores",
          4: "no LDS operand reads in the K loop", 5: "no staging and no LDS operand reads (MFMA + transform + epilogue)",
          6: "as 5, without the barrier per chunk", 7: "as 5, without the input transforms",
          8: "no raw-tile staging after the first two chunks", 9: "no U staging after the first two chunks", 10: "raw tiles all read from frame 0 (L2 hits)"}
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
-        child(sys.argv[2])
+        child(sys.argv[2], ((128, 64, 128), (128, 64, 64), (128, 64, 32), (128, 128, 32), (16, 64, 128)) if "--shapes" in sys.argv else ((128, 64, 128),))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--build":          # here (no GPU): the libraries travel with the snapshot
         for v in [int(a) for a in sys.argv[2:]] or sorted(NAMES):
             print(build_variant(v))
         sys.exit(0)
-    for v in [int(a) for a in sys.argv[1:]] or sorted(NAMES):
+    extra = [a for a in sys.argv[1:] if a.startswith("--")]
+    for v in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or sorted(NAMES):
         out = os.path.join(ROOT, "tools", "_diag", f"libc2s_w16diag{v}.so")
         if not os.path.exists(out):
             out = build_variant(v)
         print(f"variant {v}: {NAMES[v]}", flush=True)
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", out])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", out, *extra])
