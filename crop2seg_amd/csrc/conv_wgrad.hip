@@ -471,6 +471,9 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
     const float sb_ = xi == 1 ? 1.f : -1.f;                        // t = d[ra] + sb * d[rb]
     const float ga = xi == 3 ? 0.f : 1.f, gb = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);   // r = ga * gy[0] + gb * gy[1]
 
+    f32x2w sb2 = {sb_, sb_}, ga2 = {ga, ga}, gb2 = {gb, gb};
+    asm volatile("" : "+v"(sb2), "+v"(ga2), "+v"(gb2));       // (in vector registers: packed operands of v_pk_fma_f32 / v_pk_mul_f32)
+
     f32x16 acc[4][2];
 #pragma unroll
     for (int v = 0; v < 4; ++v)
@@ -607,17 +610,28 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
         for (int kk = 0; kk < 16; ++kk) {
             const f32x2w(&dd)[4] = d[kk & 1];
             const f32x2w(&gg)[2][2] = g[kk & 1];
-            // input transform (row pair of Bt, then the four columns)
-            const float t0 = fmaf(sb_, dd[2].x, dd[0].x), t1 = fmaf(sb_, dd[2].y, dd[0].y);
-            const float t2 = fmaf(sb_, dd[3].x, dd[1].x), t3 = fmaf(sb_, dd[3].y, dd[1].y);
-            const float V[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
-            // output-gradient transform (row of A, then the four columns of At)
-            float Mt[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const float r0 = fmaf(gb, gg[m][1].x, ga * gg[m][0].x), r1 = fmaf(gb, gg[m][1].y, ga * gg[m][0].y);
-                Mt[m][0] = r0; Mt[m][1] = r0 + r1; Mt[m][2] = r0 - r1; Mt[m][3] = -r1;
-            }
+            // input transform (row pair of Bt, then the four columns) and output-gradient transform (row of A, then the four
+            // columns of At) on register pairs: 10 packed VALU instructions per k-step instead of 22 scalar ones (each VALU
+            // instruction costs the SIMD ~8 cycles of MFMA issue; tools/_diag/mfma_rate.hip).  The last column pair carries a
+            // flipped sign on both operands (V3' = t3 - t1, Mt3' = r1: the product is unchanged, bit for bit).  The asm holds
+            // the three operand-select forms the compiler does not emit; its s_nop covers the VALU -> MFMA wait states.
+            f32x2w V03, V12, M0, M1, R0, R1, T01, T23;
+            asm("v_pk_fma_f32 %6, %16, %10, %8\n\t"                                            // t01 = d[ra] + sb * d[rb]
+                "v_pk_fma_f32 %7, %16, %11, %9\n\t"                                            // t23
+                "v_pk_mul_f32 %4, %17, %12\n\t"
+                "v_pk_mul_f32 %5, %17, %14\n\t"
+                "v_pk_fma_f32 %4, %18, %13, %4\n\t"                                            // r = ga * gy[0] + gb * gy[1]
+                "v_pk_fma_f32 %5, %18, %15, %5\n\t"
+                "v_pk_add_f32 %0, %6, %7 neg_lo:[0,1] neg_hi:[1,0]\n\t"                        // (t0 - t2, t3 - t1)
+                "v_pk_add_f32 %1, %6, %7 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"       // (t1 + t2, t2 - t1)
+                "v_pk_add_f32 %2, %4, %4 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"       // (r0 + r1, r0 - r1)
+                "v_pk_add_f32 %3, %5, %5 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                "s_nop 1"
+                : "=&v"(V03), "=&v"(V12), "=&v"(M0), "=&v"(M1), "=&v"(R0), "=&v"(R1), "=&v"(T01), "=&v"(T23)
+                : "v"(dd[0]), "v"(dd[1]), "v"(dd[2]), "v"(dd[3]), "v"(gg[0][0]), "v"(gg[0][1]), "v"(gg[1][0]), "v"(gg[1][1]),
+                  "v"(sb2), "v"(ga2), "v"(gb2));
+            const float V[4] = {V03.x, V12.x, V12.y, V03.y};
+            const float Mt[2][4] = {{R0.x, M0.x, M0.y, R0.y}, {R1.x, M1.x, M1.y, R1.y}};
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0], Mt[0][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
