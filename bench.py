@@ -227,7 +227,8 @@ def main():
         # where the direct form needs 36 -- the roofline fraction is priced on the EXECUTED count (<= 1 by construction)
         flops_exec = flops_algo * (16.0 / 36.0 if wino else 1.0)
         achieved = flops_exec / (kernel_ms * 1e-3) / 1e12 if ms else 0.0
-        kname = "conv_winograd_kernel<4,false>" if wino else "conv_igemm_kernel<3,1,2,false>"
+        kname = ("conv_winograd16_kernel<false>" if E._wide_winograd(H, H, 64) else "conv_winograd_kernel<4,false>") if wino \
+            else "conv_igemm_kernel<3,1,2,false>"
         traffic, traffic_src = dominant_traffic(kname, N, H)
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_F32_TFLOPS,

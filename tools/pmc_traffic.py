@@ -14,7 +14,8 @@ have to be calibrated on a known byte count in the kernel's own access pattern):
       add_kernel        (c2s_add_inplace)  dword per lane:  reads 2 x 1 GiB, writes 1 GiB
       row_stats_kernel  (c2s_norm_fwd)     16 B per lane:   reads the 512 MiB activation tensor once
   * the dominant layer of the default bench workload: 64->64 3x3 reflect @128x128, N = 128 frames, forward
-    (conv_winograd_kernel<4,false>; its input gather is dword-per-lane buffer loads, its stores are float4).
+    (conv_winograd16_kernel<false>, or conv_winograd_kernel<4,false> under C2S_WINO16=0; the input gather is dword-per-lane
+    buffer loads, the stores are float2 / float4).
 `parse` averages the raw counters per kernel, derives the read correction factor of each access width from the calibration
 kernels and writes bytes_per_launch = fetch_raw x factor(dword) + write_raw x factor(store)."""
 import csv
@@ -93,17 +94,20 @@ def parse(dir_fetch, dir_write):
     f_dword = (2.0 * ADD_FLOATS * 4) / add_f            # known bytes / reported bytes, dword-per-lane reads
     f_b128 = act / rs_f                                 # 16-B-per-lane reads
     f_store = (ADD_FLOATS * 4.0) / add_w                # dword-per-lane stores
-    wk, (wf, nf) = pick(fetch, "conv_winograd_kernel<4, false>")
-    _, (ww, nw) = pick(write, "conv_winograd_kernel<4, false>")
+    wide = any("conv_winograd16_kernel<false>" in k for k in fetch)      # the default for planes >= 32 wide (C2S_WINO16)
+    needle, key = ("conv_winograd16_kernel<false>", "conv_winograd16_kernel<false>") if wide else \
+                  ("conv_winograd_kernel<4, false>", "conv_winograd_kernel<4,false>")
+    wk, (wf, nf) = pick(fetch, needle)
+    _, (ww, nw) = pick(write, needle)
     raw_f, raw_w = wf * KiB, ww * KiB
-    # the kernel's stores are float4 (exact per the guide); its input gather is dword per lane
+    # the kernel's stores are float4 / float2 (exact per the guide); its input gather is dword per lane
     bytes_per_launch = raw_f * f_dword + raw_w
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         commit = "unknown"
     out = {
-        "conv_winograd_kernel<4,false>": {
+        key: {
             "N": N_FR, "H": HW_, "bytes_per_launch": bytes_per_launch,
             "fetch_raw_bytes": raw_f, "write_raw_bytes": raw_w, "dispatches": [nf, nw],
             "fetch_factor_dword_reads": f_dword, "fetch_factor_16B_reads": f_b128, "write_factor_dword_stores": f_store,

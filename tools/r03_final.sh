@@ -19,3 +19,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tu -- python ben
 timeout -k 10 300 python tools/tile_bench.py > $O/tile_bench.txt 2>&1 || tail -5 $O/tile_bench.txt
 tail -3 $O/tile_bench.txt
 find $O -name '*kernel_trace.csv' -delete
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python tools/pmc_traffic.py run > $O/pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python tools/pmc_traffic.py run > $O/pmc_w.log 2>&1
+python tools/pmc_traffic.py parse $O/pmc_fetch $O/pmc_write > $O/pmc_parse.log 2>&1 || tail -5 $O/pmc_parse.log
+cp profiles/dominant_kernel_traffic.json $O/
+find $O -name '*kernel_trace.csv' -delete
+find $O -name '*counter_collection.csv' -size +30M -delete
