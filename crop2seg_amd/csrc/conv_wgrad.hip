@@ -346,9 +346,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(WgradParams p) 
     int tile = next_tile((p.nslices & 7) == 0 ? (slice & 7) * (p.nslices >> 3) + (slice >> 3) : slice);
     if (tile < p.ntiles) prefetch(tile);
     while (tile < p.ntiles) {
+        // the next tile's frame flag is fetched under the LDS commit and the barrier (read right after the barrier it stalled
+        // every wave of the workgroup for a memory round trip per tile)
+        const int cand = tile + p.nslices;
+        const int cflag = (p.valid != nullptr && cand < p.ntiles) ? p.valid[cand / (p.tiles_x * p.tiles_y)] : 1;
         commit();
         __syncthreads();
-        const int nxt = next_tile(tile + p.nslices);
+        const int nxt = cflag != 0 ? cand : next_tile(cand + p.nslices);
         if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
         // operand reads software-pipelined one position-pair ahead of the MFMAs (order pinned with sched barriers)
         auto load_ops = [&](int kk, float (&a)[NA], float& b) {
@@ -600,9 +604,13 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
     int tile = next_tile((p.nslices & 7) == 0 ? (slice & 7) * (p.nslices >> 3) + (slice >> 3) : slice);
     if (tile < p.ntiles) prefetch(tile);
     while (tile < p.ntiles) {
+        // the next tile's frame flag is fetched under the LDS commit and the barrier (read right after the barrier it stalled
+        // every wave of the workgroup for a memory round trip per tile)
+        const int cand = tile + p.nslices;
+        const int cflag = (p.valid != nullptr && cand < p.ntiles) ? p.valid[cand / (p.tiles_x * p.tiles_y)] : 1;
         commit();
         __syncthreads();
-        const int nxt = next_tile(tile + p.nslices);
+        const int nxt = cflag != 0 ? cand : next_tile(cand + p.nslices);
         if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
         f32x2w d[2][4], g[2][2][2];
         load_ops(0, d[0], g[0]);

@@ -1,9 +1,10 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 120 tools/_diag/mfma_rate > gpurun_out/r03_mfma_rate.txt 2>&1
-timeout -k 10 400 python tools/wino16_diag.py 0 --shapes > gpurun_out/r03_wino16_diag.txt 2>&1 && \
-timeout -k 10 400 python tools/wino16_diag.py 1 3 5 7 10 >> gpurun_out/r03_wino16_diag.txt 2>&1 && \
-timeout -k 10 100 python tools/_diag/clock_probe.py > gpurun_out/r03_clock_probe.txt 2>&1
-grep -v amdgpu.ids gpurun_out/r03_wino16_diag.txt | tail -40
-grep "per launch" gpurun_out/r03_clock_probe.txt
+timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "conv" > gpurun_out/wg_test.log 2>&1
+echo "test rc=$?" >> gpurun_out/wg_test.log
+tail -4 gpurun_out/wg_test.log
+grep -q "test rc=0" gpurun_out/wg_test.log || exit 1
+for i in 1 2 3; do
+timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'], d['value'])" || exit 1
+done
