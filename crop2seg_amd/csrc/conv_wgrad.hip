@@ -489,6 +489,33 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
     f32x4 xi4[XI_PT];
     float xh[XH_PT];
     f32x4 gv[G_PT];
+    // Tile-invariant byte offsets of this thread's float4 items (input rows, gradient rows) inside a frame: on tiles that
+    // touch neither the top nor the bottom of the plane the requests are buffer loads at (offset, scalar tile offset) with no
+    // per-tile address arithmetic in the vector ALU (it was 287 VALU instructions per tile next to 128 MFMAs; a VALU
+    // instruction costs ~8 cycles of MFMA issue).  Channels past the end of a source are out-of-range offsets (read 0).
+    int xoff[XI_PT], gof[G_PT];
+    unsigned xs1 = 0;                                   // bit i: item i comes from the second source (uniform per wave)
+    const bool fast_ok = CB == 2 && (p.C1 == 0 || p.C0 % 8 == 0) &&      // (CB == 1 has no registers to spare for the offsets)
+                         (long)(p.C0 > p.C1 ? p.C0 : p.C1) * HW * 4 < 0x7FFF0000L &&
+                         (long)p.Cout * HW * 4 < 0x7FFF0000L;
+#pragma unroll
+    for (int i = 0; i < XI_PT; ++i) {
+        const int e = tid + i * NTH;
+        const int j = e & 7, rr = e >> 3;
+        const int c = rr % CW, r = rr / CW;
+        const int cg = cb0 + c;
+        const bool second = cg >= p.C0;
+        xoff[i] = (((second ? cg - p.C0 : cg) * HW) + r * p.Win + 4 * j) * 4;
+        xs1 |= (unsigned)__builtin_amdgcn_readfirstlane(second ? 1 : 0) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < G_PT; ++i) {
+        const int e = tid + i * NTH;
+        const int j = e & 7, rr = e >> 3;
+        const int o = rr & 63, r = rr >> 6;
+        gof[i] = (o * HW + r * p.Win + 4 * j) * 4;
+    }
+    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
     auto prefetch = [&](int tile) {
         const int n = tile / (p.tiles_x * p.tiles_y);
         const int trem = tile - n * (p.tiles_x * p.tiles_y);
@@ -496,21 +523,50 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
         const int oy0 = tyi * 4, ox0 = txi * 32;
         const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
         const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HW : nullptr;
+        const float* gn = p.gout + (size_t)n * p.Cout * HW;
+        const bool fast = fast_ok && oy0 > 0 && oy0 + 4 < p.Hin;
+        if (fast) {
+            const __amdgpu_buffer_rsrc_t q0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HW * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t q1 =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(s1n != nullptr ? s1n : s0n), 0, p.C1 * HW * 4, 0x00020000);
+            const int so = ((oy0 - 1) * p.Win + ox0) * 4;
 #pragma unroll
-        for (int i = 0; i < XI_PT; ++i) {
-            const int e = tid + i * NTH;
-            const int j = e & 7, rr = e >> 3;
-            const int c = rr % CW, r = rr / CW;
-            int gy = oy0 - 1 + r;
-            bool ok = true;
-            if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
-            const int cg = cb0 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok && cg < Cin) {
-                const float* sp = cg < p.C0 ? s0n + (size_t)cg * HW : s1n + (size_t)(cg - p.C0) * HW;
-                v = *reinterpret_cast<const f32x4*>(sp + (size_t)gy * p.Win + ox0 + 4 * j);
+            for (int i = 0; i < XI_PT; ++i) {
+                const u32x4w v = ((xs1 >> i) & 1u) ? __builtin_amdgcn_raw_buffer_load_b128(q1, xoff[i], so, 0)
+                                                   : __builtin_amdgcn_raw_buffer_load_b128(q0, xoff[i], so, 0);
+                xi4[i] = __builtin_bit_cast(f32x4, v);
             }
-            xi4[i] = v;
+            const __amdgpu_buffer_rsrc_t qg =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(gn + (size_t)ob * HW), 0, (p.Cout - ob) * HW * 4, 0x00020000);
+            const int sg = (oy0 * p.Win + ox0) * 4;
+#pragma unroll
+            for (int i = 0; i < G_PT; ++i) gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qg, gof[i], sg, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < XI_PT; ++i) {
+                const int e = tid + i * NTH;
+                const int j = e & 7, rr = e >> 3;
+                const int c = rr % CW, r = rr / CW;
+                int gy = oy0 - 1 + r;
+                bool ok = true;
+                if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
+                const int cg = cb0 + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok && cg < Cin) {
+                    const float* sp = cg < p.C0 ? s0n + (size_t)cg * HW : s1n + (size_t)(cg - p.C0) * HW;
+                    v = *reinterpret_cast<const f32x4*>(sp + (size_t)gy * p.Win + ox0 + 4 * j);
+                }
+                xi4[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < G_PT; ++i) {
+                const int e = tid + i * NTH;
+                const int j = e & 7, rr = e >> 3;
+                const int o = rr & 63, r = rr >> 6;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ob + o < p.Cout) v = *reinterpret_cast<const f32x4*>(gn + (size_t)(ob + o) * HW + (size_t)(oy0 + r) * p.Win + ox0 + 4 * j);
+                gv[i] = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < XH_PT; ++i) {
@@ -531,16 +587,6 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
                 }
             }
             xh[i] = v;
-        }
-        const float* gn = p.gout + (size_t)n * p.Cout * HW;
-#pragma unroll
-        for (int i = 0; i < G_PT; ++i) {
-            const int e = tid + i * NTH;
-            const int j = e & 7, rr = e >> 3;
-            const int o = rr & 63, r = rr >> 6;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ob + o < p.Cout) v = *reinterpret_cast<const f32x4*>(gn + (size_t)(ob + o) * HW + (size_t)(oy0 + r) * p.Win + ox0 + 4 * j);
-            gv[i] = v;
         }
     };
     auto commit = [&]() {

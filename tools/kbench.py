@@ -8,7 +8,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from crop2seg_amd import _lib, engine as E  # noqa: E402
+from crop2seg_amd import _lib  # noqa: E402
+if os.environ.get("C2S_KBENCH_LIB"):          # A/B runs against an older build of the library
+    _lib.LIB_PATH = os.environ["C2S_KBENCH_LIB"]
+from crop2seg_amd import engine as E  # noqa: E402
 
 L = _lib
 
@@ -72,8 +75,10 @@ def main():
         y = E.conv2d(ctx, [x], "w", "b", K, S, pad, mode, None)
         KK = K * K
 
+        vflags = torch.ones(N, dtype=torch.int32, device=dev)      # frame flags as in a training step (all real)
+
         def wgrad():
-            E._wgrad(ctx, [x], gy, Cout, Ho, Ho, K, S, pad, mode, grads["w"], Cin * KK, KK, list(range(KK)), 0, None)
+            E._wgrad_launch(ctx, [x], gy, Cout, Ho, Ho, K, S, pad, mode, grads["w"], Cin * KK, KK, list(range(KK)), 0, vflags)
         t_w = time_fn(wgrad, args.reps)
 
         # backward (wgrad + dgrad) timed alone: the forward that builds the tape runs outside the events
