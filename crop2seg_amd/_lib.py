@@ -81,6 +81,10 @@ SIGNATURES = {
     "c2s_wgrad_workspace_floats": (SZ, [C.POINTER(WgradDesc)]),
     "c2s_conv_wgrad": (I, [C.POINTER(WgradDesc), P, P, P, P, SZ, P, P]),
     "c2s_wgrad_reduce": (I, [C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, P]),
+    "c2s_wgrad_reduce_job_bytes": (SZ, []),
+    "c2s_wgrad_reduce_job_blocks": (I, [C.POINTER(WgradDesc)]),
+    "c2s_wgrad_reduce_job_fill": (I, [P, C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, I]),
+    "c2s_wgrad_reduce_batch": (I, [P, I, I, P]),
     "c2s_dwconv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "c2s_dwconv_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "c2s_dwconv_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

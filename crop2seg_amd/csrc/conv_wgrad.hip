@@ -899,6 +899,71 @@ extern "C" int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const 
     return C2S_EINVAL;
 }
 
+// ---- all slice sums of a backward pass in ONE launch (26 launches of a few dozen workgroups each in a U-TAE step): the
+// caller keeps one slab buffer per layer, builds a table of job records once and reuses it every step (as c2s_pack_batch)
+namespace {
+struct ReduceJob {
+    const float* slabs;
+    float* dst;
+    long so, sc;
+    int nslices, NT, Cin, Cout, CinP, CoutB, accumulate, block_start;
+    int taps[16];
+};
+
+__global__ void wgrad_reduce_batch_kernel(const ReduceJob* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;      // a few dozen jobs: linear scan
+    const ReduceJob& jb = jobs[j];
+    const long total = (long)jb.NT * jb.Cin * jb.Cout;
+    const long e = (long)(blockIdx.x - jb.block_start) * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int o = (int)(e % jb.Cout);
+    const long tc = e / jb.Cout;
+    const int c = (int)(tc % jb.Cin), t = (int)(tc / jb.Cin);
+    const size_t stride = (size_t)jb.NT * jb.CinP * jb.CoutB;
+    const float* s = jb.slabs + ((size_t)t * jb.CinP + c) * jb.CoutB + o;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // same order of additions as wgrad_reduce_kernel
+    int k = 0;
+    for (; k + 8 <= jb.nslices; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] += s[(size_t)(k + u) * stride];
+    }
+    for (int u = 0; k < jb.nslices; ++k, ++u) part[u] += s[(size_t)k * stride];
+    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    float* d = jb.dst + o * jb.so + c * jb.sc + jb.taps[t];
+    *d = jb.accumulate ? *d + acc : acc;
+}
+}  // namespace
+
+extern "C" size_t c2s_wgrad_reduce_job_bytes(void) { return sizeof(ReduceJob); }
+
+extern "C" int c2s_wgrad_reduce_job_blocks(const c2s_wgrad_desc* d) {
+    if (int rc = check(d)) return rc;
+    return cdiv((long)d->KH * d->KW * (d->C0 + d->C1) * d->Cout, 256);
+}
+
+extern "C" int c2s_wgrad_reduce_job_fill(void* host_record, const c2s_wgrad_desc* d, const float* slabs, float* dst,
+                                         long stride_o, long stride_c, const int* host_tap_off, int accumulate, int block_start) {
+    if (int rc = check(d)) return rc;
+    C2S_REQUIRE(host_record && slabs && dst && host_tap_off && block_start >= 0, "wgrad_reduce_job_fill: bad args");
+    ReduceJob* j = reinterpret_cast<ReduceJob*>(host_record);
+    const int NT = d->KH * d->KW, Cin = d->C0 + d->C1;
+    j->slabs = slabs; j->dst = dst; j->so = stride_o; j->sc = stride_c;
+    j->nslices = d->nslices; j->NT = NT; j->Cin = Cin; j->Cout = d->Cout;
+    j->CinP = cdiv(Cin, 32) * 32; j->CoutB = cdiv(d->Cout, 64) * 64;
+    j->accumulate = accumulate; j->block_start = block_start;
+    for (int i = 0; i < 16; ++i) j->taps[i] = i < NT ? host_tap_off[i] : 0;
+    return C2S_OK;
+}
+
+extern "C" int c2s_wgrad_reduce_batch(const void* device_table, int njobs, int total_blocks, void* stream) {
+    C2S_REQUIRE(device_table && njobs > 0 && total_blocks > 0, "wgrad_reduce_batch: bad args");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const ReduceJob*>(device_table), njobs);
+    C2S_CHECK_LAUNCH("wgrad_reduce_batch");
+    return C2S_OK;
+}
+
 extern "C" int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, float* dst, long stride_o, long stride_c,
                                 const int* host_tap_off, int accumulate, void* stream) {
     if (int rc = check(d)) return rc;

@@ -68,6 +68,8 @@ class Workspace:
         # weight-pack plan: the jobs recorded during one step become a device table that later steps run in one launch
         self.pack_record: Dict[Tuple, Tuple] = {}
         self.pack_plan: Optional[dict] = None
+        self.reduce_jobs: List[Tuple] = []          # slice sums of the weight gradients recorded during this backward pass
+        self.reduce_plan: Optional[dict] = None     # their one-launch table (built once, reused while the jobs stay the same)
 
     def finalize_pack_plan(self) -> None:
         """Turn the packs recorded during the step that just ran into a one-launch plan (host -> device table copy:
@@ -88,6 +90,31 @@ class Workspace:
             outs[key] = (out, src_ptr)
         self.pack_plan = {"table": table.to(self.device), "njobs": len(jobs), "blocks": block, "outs": outs}
         self.pack_record = {}
+
+    def run_reduce_batch(self) -> None:
+        """Sum the split-K slabs of every weight gradient recorded during this backward pass in one launch
+        (c2s_wgrad_reduce_batch).  The job table is built on the host the first time (and again if a job changed) -- outside
+        hipGraph capture; under capture a matching table must exist, otherwise the sums are launched one by one."""
+        jobs, self.reduce_jobs = self.reduce_jobs, []
+        if not jobs:
+            return
+        L_ = lib()
+        key = tuple(j[:-1] for j in jobs)
+        plan = self.reduce_plan
+        if plan is None or plan["key"] != key:
+            if torch.cuda.is_current_stream_capturing():
+                for (dbytes, slabs_ptr, dst_ptr, so, sc, taps, acc, d) in jobs:
+                    check(L_.c2s_wgrad_reduce(C.byref(d), slabs_ptr, dst_ptr, so, sc, _tap_array(taps), acc, _stream()), "wgrad_reduce")
+                return
+            rec = L_.c2s_wgrad_reduce_job_bytes()
+            table = torch.zeros(len(jobs) * rec, dtype=torch.uint8).pin_memory()
+            block = 0
+            for i, (dbytes, slabs_ptr, dst_ptr, so, sc, taps, acc, d) in enumerate(jobs):
+                check(L_.c2s_wgrad_reduce_job_fill(table.data_ptr() + i * rec, C.byref(d), slabs_ptr, dst_ptr, so, sc,
+                                                   _tap_array(taps), acc, block), "wgrad_reduce_job_fill")
+                block += L_.c2s_wgrad_reduce_job_blocks(C.byref(d))
+            plan = self.reduce_plan = {"key": key, "table": table.to(self.device), "njobs": len(jobs), "blocks": block}
+        check(L_.c2s_wgrad_reduce_batch(plan["table"].data_ptr(), plan["njobs"], plan["blocks"], _stream()), "wgrad_reduce_batch")
 
     def sync_area(self, nbytes: int) -> Tensor:
         """Zero-initialised area for kernels whose workgroups meet through memory (one-pass normalisation): all zero at rest
@@ -122,6 +149,7 @@ class Tape:
         self.side_keep: List[Tensor] = []  # operands of kernels running on the side stream (alive until the join)
         self.side_used = False
         self.side_pending: List[Callable[[], None]] = []   # weight-gradient launches waiting for the next fork
+        self.finalizers: Dict[int, Callable[[], None]] = {}   # run once after the last side-stream launch (batched slice sums)
 
     def fork(self) -> "torch.cuda.Stream":
         """Side HIP stream ordered after everything issued so far on the current stream.  Weight gradients feed nothing
@@ -175,6 +203,15 @@ class Tape:
         for fn in reversed(self.ops):
             fn()
         self.flush_side()
+        if self.finalizers:
+            fins, self.finalizers = list(self.finalizers.values()), {}
+            if self.side_used:                      # after the weight-gradient kernels, on their stream
+                with torch.cuda.stream(_side_stream()):
+                    for fn in fins:
+                        fn()
+            else:
+                for fn in fins:
+                    fn()
         if self.side_used:
             ev = torch.cuda.Event()
             ev.record(_side_stream())
@@ -321,6 +358,10 @@ import os as _os
 
 CONV_MODE = _os.environ.get("C2S_CONV_MODE", "f32")
 assert CONV_MODE in ("f32", "bf16x3"), CONV_MODE
+# C2S_REDUCE_BATCH=1: the split-K slice sums of all weight gradients of a backward pass in one launch at its end (one slab
+# buffer per layer) instead of one launch per layer right behind its weight-gradient kernel.  Measured neutral on the eager
+# two-stream step (11.70 vs 11.71 ms), -0.2 ms under hipGraph capture (12.3 -> 12.1 ms): off by default.
+REDUCE_BATCH = _os.environ.get("C2S_REDUCE_BATCH", "0") != "0"
 # fp32 Winograd F(2x2,3x3) for the wide 3x3 layers (forward + data gradient); C2S_WINOGRAD=0 keeps the direct kernel.
 WINOGRAD = _os.environ.get("C2S_WINOGRAD", "1") != "0"
 # the 8-wave Winograd kernel with the output transform in registers (conv_winograd16.hip) for planes >= 32 wide;
@@ -412,11 +453,17 @@ def _wgrad_launch(ctx: Ctx, srcs: Sequence[Tensor], gout: Tensor, Cout: int, Hou
     d = WgradDesc(N, C0, C1, Hin, Win, Cout, Hout, Wout, K, K, S, pad, pad, pad_mode,
                   _wgrad_slices(ctx, N, Hout, Wout, S, C0 + C1, Cout))
     nfl = lib().c2s_wgrad_workspace_floats(C.byref(d))
-    slabs = ctx.ws.get("wgrad_slabs", nfl)
+    batched = REDUCE_BATCH and ctx.tape is not None and not accumulate
+    # batched slice sums: one slab buffer per weight (they all live until the end of the backward pass)
+    slabs = ctx.ws.get(f"wgrad_slabs:{dst.data_ptr()}:{so}:{taps[0]}" if batched else "wgrad_slabs", nfl)
     check(lib().c2s_conv_wgrad(C.byref(d), s0.data_ptr(), _ptr(s1), gout.data_ptr(), slabs.data_ptr(), slabs.numel(),
                                _ptr(valid), _stream()), "conv_wgrad")
-    check(lib().c2s_wgrad_reduce(C.byref(d), slabs.data_ptr(), dst.data_ptr(), so, sc, _tap_array(taps), accumulate,
-                                 _stream()), "wgrad_reduce")
+    if batched:
+        ctx.ws.reduce_jobs.append((bytes(d), slabs.data_ptr(), dst.data_ptr(), so, sc, tuple(taps), accumulate, d))
+        ctx.tape.finalizers[id(ctx.ws)] = ctx.ws.run_reduce_batch
+    else:
+        check(lib().c2s_wgrad_reduce(C.byref(d), slabs.data_ptr(), dst.data_ptr(), so, sc, _tap_array(taps), accumulate,
+                                     _stream()), "wgrad_reduce")
 
 
 def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K: int, S: int, pad: int,

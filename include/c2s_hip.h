@@ -190,6 +190,15 @@ int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const float* src1
                    float* slabs, size_t slab_floats, const int* valid, void* stream);
 int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, float* dst, long stride_o, long stride_c,
                      const int* host_tap_off, int accumulate, void* stream);
+/* All slice sums of a backward pass in one launch: one slab buffer per layer, a table of job records (record size
+ * c2s_wgrad_reduce_job_bytes(), filled by c2s_wgrad_reduce_job_fill with the arguments of c2s_wgrad_reduce; block_start of
+ * job i = sum of c2s_wgrad_reduce_job_blocks over the jobs before it) built once on the host, uploaded, and passed to
+ * c2s_wgrad_reduce_batch(device_table, njobs, total_blocks) every step.  Same order of additions as c2s_wgrad_reduce. */
+size_t c2s_wgrad_reduce_job_bytes(void);
+int c2s_wgrad_reduce_job_blocks(const c2s_wgrad_desc* d);
+int c2s_wgrad_reduce_job_fill(void* host_record, const c2s_wgrad_desc* d, const float* slabs, float* dst, long stride_o,
+                              long stride_c, const int* host_tap_off, int accumulate, int block_start);
+int c2s_wgrad_reduce_batch(const void* device_table, int njobs, int total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Depthwise convolution (groups = C, no bias) forward / data gradient / weight gradient.

@@ -38,6 +38,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda")
     E.CONV_MODE = args.mode
+    E.REDUCE_BATCH = False          # time each weight gradient with its own slice sum
     shapes = [  # name, N, Cin, Cout, H, K, S, pad, mode
         ("in_conv.3   64->64  3x3 @128", 128, 64, 64, 128, 3, 1, 1, L.PAD_REFLECT),
         ("in_conv.0   10->64  3x3 @128", 128, 10, 64, 128, 3, 1, 1, L.PAD_REFLECT),

@@ -1,4 +1,12 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-for v in v1 v2 v3; do echo "== wgrad $v"; C2S_KBENCH_LIB=tools/_diag/libs/libc2s_wgrad_$v.so timeout -k 10 200 python tools/kbench.py --reps 7 --only "3x3 @" 2>&1 | grep -v amdgpu.ids | cut -c1-37,62- ; done
+timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py -x -q -m gpu > gpurun_out/wg_test.log 2>&1
+echo "test rc=$?" >> gpurun_out/wg_test.log
+tail -4 gpurun_out/wg_test.log
+grep -q "test rc=0" gpurun_out/wg_test.log || exit 1
+for i in 1 2 3; do
+C2S_REDUCE_BATCH=0 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch=0', d['ms_per_step'], d['value'])" && \
+timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch=1', d['ms_per_step'], d['value'])" || exit 1
+done
+timeout -k 10 300 python bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('graph', d['ms_per_step'], d['value'])"
