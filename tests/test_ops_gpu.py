@@ -141,6 +141,42 @@ def test_conv2d_wide_winograd(case):
     assert rel(ctx.g["w"], w.grad) < 5e-6
 
 
+def test_weight_gradient_slice_sums_batched():
+    """C2S_REDUCE_BATCH: the split-K slabs of every layer are summed by ONE launch at the end of the backward pass
+    (c2s_wgrad_reduce_batch); two stacked convolutions (3x3 Winograd path and 4x4 stride 2), two backward passes so that the
+    job table is built once and reused once; same order of additions as the per-layer launches: bit-identical gradients."""
+    E, L = _engine()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    w1 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    w2 = torch.randn(64, 64, 4, 4, generator=g) / 32
+    results = {}
+    for batched in (False, True):
+        old = E.REDUCE_BATCH
+        E.REDUCE_BATCH = batched
+        try:
+            ctx0 = make_ctx({"w1": w1, "w2": w2})
+            xd = x.cuda()
+            for _ in range(2):                          # a fresh context per step on the same workspace, as TrainStep does
+                ctx = E.Ctx(ctx0.p, ctx0.b, ctx0.g, ctx0.ws, True, E.Tape())
+                h = E.conv2d(ctx, [xd], "w1", None, 3, 1, 1, L.PAD_REFLECT, None, need_input_grad=False)
+                y = E.conv2d(ctx, [h], "w2", None, 4, 2, 1, L.PAD_REFLECT, None)
+                gout = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+                seed_backward(ctx, y, gout)
+            torch.cuda.synchronize()
+            results[batched] = (ctx.g["w1"].clone(), ctx.g["w2"].clone())
+            if batched:
+                assert ctx.ws.reduce_plan is not None and ctx.ws.reduce_plan["njobs"] == 2 and not ctx.ws.reduce_jobs
+        finally:
+            E.REDUCE_BATCH = old
+    assert torch.equal(results[True][0], results[False][0]) and torch.equal(results[True][1], results[False][1])
+    xr = x.clone().requires_grad_(True)
+    w1r, w2r = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    yr = O.conv2d(O.conv2d(xr, w1r, None, 1, 1, "reflect"), w2r, None, 2, 1, "reflect")
+    yr.backward(torch.randn(yr.shape, generator=torch.Generator().manual_seed(3)))
+    assert rel(results[True][0], w1r.grad) < 5e-6 and rel(results[True][1], w2r.grad) < 5e-6
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 64, 4, 4), (2, 64, 32, 16, 16), (1, 32, 32, 64, 64)])
 def test_conv_transpose_fwd_bwd(shape):
     E, L = _engine()
