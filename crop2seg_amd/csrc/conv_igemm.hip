@@ -277,17 +277,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         const int oy = oy0 + f * FR + fy, ox = ox0 + fx;
         if (oy >= p.Hout || ox >= p.Wout) continue;
         const size_t sp = (size_t)(oy * p.osy + p.ooy) * p.OutW + (ox * p.osx + p.oox);
+        // (accumulation: eight reads in flight, then their adds and stores -- read-add-store per element serialised 32 memory
+        // round trips, the compiler cannot move a read above the store before it)
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (co < p.Cout) {
-                    float v = acc[m][q][r];
-                    if (p.bias != nullptr) v += p.bias[co];
-                    float* dst = on + (size_t)co * outHW + sp;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float old[8];
+                if (p.accumulate) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = r0 + u;
+                        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        old[u] = co < p.Cout ? on[(size_t)co * outHW + sp] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u;
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (co < p.Cout) {
+                        float v = acc[m][q][r];
+                        if (p.bias != nullptr) v += p.bias[co];
+                        if (p.accumulate) v += old[u];
+                        on[(size_t)co * outHW + sp] = v;
+                    }
                 }
             }
         }

@@ -215,17 +215,32 @@ __global__ __launch_bounds__(256) void conv_xpair_kernel(XpParams p) {
     if (oy >= p.Hout || ox >= p.Wout) return;
     const size_t outHW = (size_t)p.OutH * p.OutW;
     float* on = p.out + (size_t)n * p.Cout * outHW + (size_t)(oy * 2 + p.ooy) * p.OutW + 2 * ox;
+    // accumulation into an existing gradient: the reads of EIGHT elements first, then their adds and stores (read-add-store per
+    // element made every read wait for the store before it -- the compiler cannot reorder them: 32 memory round trips in a
+    // row; eight at a time keeps the kernel at three workgroups per CU)
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (co < p.Cout) {
-                float2 v = make_float2(acc[m][0][r], acc[m][1][r]);
-                if (p.bias != nullptr) { v.x += p.bias[co]; v.y += p.bias[co]; }
-                float2* dst = reinterpret_cast<float2*>(on + (size_t)co * outHW);
-                if (p.accumulate) { const float2 o = *dst; v.x += o.x; v.y += o.y; }
-                *dst = v;
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float2 old[8];
+            if (p.accumulate) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u;
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    old[u] = co < p.Cout ? *reinterpret_cast<const float2*>(on + (size_t)co * outHW) : make_float2(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u;
+                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co < p.Cout) {
+                    float2 v = make_float2(acc[m][0][r], acc[m][1][r]);
+                    if (p.bias != nullptr) { v.x += p.bias[co]; v.y += p.bias[co]; }
+                    if (p.accumulate) { v.x += old[u].x; v.y += old[u].y; }
+                    *reinterpret_cast<float2*>(on + (size_t)co * outHW) = v;
+                }
             }
         }
     }

@@ -6,7 +6,7 @@ echo "test rc=$?" >> gpurun_out/wg_test.log
 tail -4 gpurun_out/wg_test.log
 grep -q "test rc=0" gpurun_out/wg_test.log || exit 1
 for i in 1 2 3; do
-C2S_REDUCE_BATCH=0 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch=0', d['ms_per_step'], d['value'])" && \
-timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch=1', d['ms_per_step'], d['value'])" || exit 1
+timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'], d['value'])" || exit 1
 done
-timeout -k 10 300 python bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('graph', d['ms_per_step'], d['value'])"
+timeout -k 10 300 python bench.py --model timeunet --batch 8 --T 61 --steps 15 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('timeunet', d['ms_per_step'], d['value'])"
+timeout -k 10 300 python bench.py --model wtae --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('wtae', d['ms_per_step'], d['value'])"
