@@ -369,6 +369,11 @@ WINOGRAD = _os.environ.get("C2S_WINOGRAD", "1") != "0"
 WINO16 = _os.environ.get("C2S_WINO16", "1") != "0"
 
 
+# Winograd F(2x2,2x2) over the input parities for the 4x4 stride-2 forward convolutions (conv_s2wino.hip); C2S_S2WINO=0 keeps
+# the direct kernel
+S2WINO = _os.environ.get("C2S_S2WINO", "1") != "0"
+
+
 def _wide_winograd(H: int, W: int, cin: int) -> bool:
     """c2s_conv3x3_winograd16_supported on top of _use_winograd: planes >= 32 wide, at least four chunks of 8 channels."""
     return WINO16 and W >= 32 and H >= 8 and cin > 24
@@ -491,6 +496,19 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
         check(lib().c2s_conv3x3_bf16x3(C.byref(d), s0.data_ptr(), _ptr(s1), whi.data_ptr(), wlo.data_ptr(),
                                        _ptr(ctx.p[bname] if bname else None), out.data_ptr(), _ptr(valid), _stream()),
               "conv3x3_bf16x3")
+    elif (S2WINO and CONV_MODE == "f32" and K == 4 and S == 2 and C1 == 0 and lib().c2s_conv4x4s2_winograd_supported(C.byref(
+            ConvDesc(N, C0, 0, Hin, Win, Cout, (Cout + 63) // 64 * 64, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)))):
+        CoutP = (Cout + 63) // 64 * 64
+        key = (wname, "fwd", "s2w")
+        upk = ctx._packed.get(key)
+        if upk is None:
+            upk = torch.empty(lib().c2s_s2wino_packed_floats(Cin, CoutP), device=ctx.device, dtype=torch.float32)
+            check(lib().c2s_pack_weights_s2wino(W.data_ptr(), upk.data_ptr(), Cin, Cout, CoutP, Cin * KK, KK, _tap_array(list(range(KK))),
+                                                _stream()), "pack_weights_s2wino")
+            ctx._packed[key] = upk
+        d = ConvDesc(N, C0, 0, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
+        check(lib().c2s_conv4x4s2_winograd(C.byref(d), s0.data_ptr(), upk.data_ptr(), _ptr(ctx.p[bname] if bname else None),
+                                           out.data_ptr(), _ptr(valid), _stream()), "conv4x4s2_winograd")
     else:
         wpk, CoutP = ctx.pack((wname, "fwd"), W, 0, Cin, Cout, KK, Cin * KK, KK, list(range(KK)))
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)

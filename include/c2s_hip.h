@@ -155,6 +155,22 @@ int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0, const floa
                            const float* bias, float* out, const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 4x4 stride-2 pad-1 convolution (forward) as Winograd F(2x2,2x2) over the four input parities (conv_s2wino.hip): 36 instead
+ * of 64 multiplies per (cin, cout) pair and 2x2 output block, integer transform matrices.  Descriptor as c2s_conv_igemm with
+ * KH = KW = 4, S = 2, pad = 1, one source with an even number (>= 8) of channels, Hin = 2 Hout, Win = 2 Wout, even output
+ * planes at least 32 wide and 8 high, dense output, CoutP a multiple of 64 (c2s_conv4x4s2_winograd_supported).
+ * upk = c2s_pack_weights_s2wino (c2s_s2wino_packed_floats(Cin, CoutP) floats, [cout block][chunk of 2 channels][2][4 parities]
+ * [64][12]; 16-entry tap table as for c2s_pack_weights).
+ * Replaces: nn.Conv2d(4, stride 2, padding 1) forward of DownConvBlock (conv.py:263-271).
+ * ------------------------------------------------------------------------------------------------ */
+size_t c2s_s2wino_packed_floats(int cin, int coutP);
+int c2s_pack_weights_s2wino(const float* src, float* upk, int cin, int cout, int coutP, long stride_o, long stride_c,
+                            const int* host_tap_off, void* stream);
+int c2s_conv4x4s2_winograd_supported(const c2s_conv_desc* d);
+int c2s_conv4x4s2_winograd(const c2s_conv_desc* d, const float* src, const float* upk, const float* bias, float* out,
+                           const int* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Opt-in split-precision variant of the 3x3 stride-1 pad-1 convolution (forward and data gradient, same
  * descriptor as c2s_conv_igemm): every fp32 operand is split into two bf16 halves (hi + lo, 16 significant bits)
  * and each product evaluated with three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi) accumulating in fp32

@@ -141,6 +141,54 @@ def test_conv2d_wide_winograd(case):
     assert rel(ctx.g["w"], w.grad) < 5e-6
 
 
+S2WINO_CASES = [
+    # N, Cin, Cout, Hin, Win, mode
+    (2, 64, 64, 128, 128, "reflect"),
+    (3, 64, 64, 64, 64, "reflect"),             # padded frame 1; one tile column
+    (2, 32, 128, 64, 64, "reflect"),            # two blocks of output channels
+    (1, 8, 72, 24, 80, "reflect"),              # ragged: partial tiles in both directions, padded output channels, 4 chunks
+    (2, 10, 64, 16, 64, "zeros"),               # one tile per frame, zero padding
+]
+
+
+@pytest.mark.parametrize("case", S2WINO_CASES)
+def test_conv4x4s2_winograd(case):
+    """The F(2x2,2x2)-over-parities kernel for the 4x4 stride-2 forward convolution (conv_s2wino.hip; C2S_S2WINO) against the
+    oracle; the backward pass of the same layer (transposed-row data gradient, direct weight gradient) is unchanged."""
+    E, L = _engine()
+    N, Cin, Cout, Hin, Win, mode = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
+    x = torch.randn(N, Cin, Hin, Win, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) / math.sqrt(Cin * 16)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    valid = torch.ones(N, dtype=torch.int32)
+    if N >= 3:
+        valid[1] = 0
+    keep = valid.bool()
+    ref = O.conv2d(x[keep], w, b, 2, 1, mode)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    ctx = make_ctx({"w": w.detach(), "b": b.detach()})
+    xd = x.detach().cuda()
+    pm = L.PAD_REFLECT if mode == "reflect" else L.PAD_ZEROS
+    old = E.S2WINO
+    E.S2WINO = True
+    try:
+        import ctypes as C
+        d = L.ConvDesc(N, Cin, 0, Hin, Win, Cout, (Cout + 63) // 64 * 64, Hin // 2, Win // 2, Hin // 2, Win // 2, 4, 4, 2, 1, 1, pm, 1, 1, 0, 0, 0)
+        assert E.lib().c2s_conv4x4s2_winograd_supported(C.byref(d)) == 1
+        out = E.conv2d(ctx, [xd], "w", "b", 4, 2, 1, pm, valid.cuda())
+        assert ("w", "fwd", "s2w") in ctx._packed
+        assert rel(out[keep.cuda()], ref) < 2e-6
+        gfull = torch.zeros(N, *ref.shape[1:])
+        gfull[keep] = gout
+        seed_backward(ctx, out, gfull)
+    finally:
+        E.S2WINO = old
+    assert rel(ctx.tape.grads[xd.data_ptr()][keep.cuda()], x.grad[keep]) < 5e-6
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+
+
 def test_weight_gradient_slice_sums_batched():
     """C2S_REDUCE_BATCH: the split-K slabs of every layer are summed by ONE launch at the end of the backward pass
     (c2s_wgrad_reduce_batch); two stacked convolutions (3x3 Winograd path and 4x4 stride 2), two backward passes so that the
