@@ -427,7 +427,7 @@ struct PackJob {
     float* dst;
     long so, sc;
     int cin, cout, coutP, ntaps;
-    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U   2: Winograd U in the 8-wave kernel's layout
+    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U   2: Winograd U in the 8-wave kernel's layout   3: conv_s2wino.hip's
     int block_start;     // first block of this job
     int taps[16];
 };
@@ -444,6 +444,33 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
         const long tc = e / jb.coutP;
         const int c = (int)(tc % jb.cin), t = (int)(tc / jb.cin);
         jb.dst[e] = o < jb.cout ? jb.src[o * jb.so + c * jb.sc + jb.taps[t]] : 0.f;
+        return;
+    }
+    if (jb.kind == 3) {          // F(2x2,2x2) parity sub-filters of a 4x4 stride-2 filter (conv_s2wino.hip): [cout block][chunk][2 c][4][64 o][12]
+        const int nch2 = (jb.cin + 1) / 2;
+        const long total3 = (long)nch2 * 2 * 4 * jb.coutP;
+        if (e >= total3) return;
+        const int o = (int)(e % jb.coutP);
+        const int par = (int)((e / jb.coutP) & 3), c = (int)(e / jb.coutP / 4);
+        const int py = par >> 1, px = par & 1;
+        const bool real = o < jb.cout && c < jb.cin;
+        float g2[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ky = (py == 0 ? 1 : 0) + 2 * a, kx = (px == 0 ? 1 : 0) + 2 * b;
+                g2[a][b] = real ? jb.src[o * jb.so + c * jb.sc + jb.taps[ky * 4 + kx]] : 0.f;
+            }
+        float* base = jb.dst + ((((size_t)(o >> 6) * nch2 + (c >> 1)) * 2 + (c & 1)) * 4 + par) * 64 * 12 + (size_t)(o & 63) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float u0 = i == 0 ? g2[0][0] : (i == 1 ? g2[0][0] + g2[1][0] : g2[1][0]);
+            const float u1 = i == 0 ? g2[0][1] : (i == 1 ? g2[0][1] + g2[1][1] : g2[1][1]);
+            base[i * 3 + 0] = u0;
+            base[i * 3 + 1] = u0 + u1;
+            base[i * 3 + 2] = u1;
+        }
         return;
     }
     const int nchunks = (jb.cin + WN_CK - 1) / WN_CK;
@@ -510,7 +537,7 @@ extern "C" size_t c2s_pack_job_bytes(void) { return sizeof(PackJob); }
 // Fill one job record of a host-side table (the caller uploads the table once and reuses it every step)
 extern "C" int c2s_pack_job_fill(void* host_record, const float* src, float* dst, int cin, int cout, int coutP, int ntaps,
                                  long stride_o, long stride_c, int winograd, const int* host_tap_off, int block_start) {
-    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16 && winograd >= 0 && winograd <= 2,
+    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16 && winograd >= 0 && winograd <= 3,
                 "pack_job_fill: bad args");
     PackJob* j = reinterpret_cast<PackJob*>(host_record);
     j->src = src; j->dst = dst; j->so = stride_o; j->sc = stride_c;
@@ -521,7 +548,8 @@ extern "C" int c2s_pack_job_fill(void* host_record, const float* src, float* dst
 
 // blocks (of 256 threads) a job needs
 extern "C" int c2s_pack_job_blocks(int cin, int coutP, int ntaps, int winograd) {
-    const long total = winograd ? (long)cdiv(cin, WN_CK) * WN_CK * coutP : (long)ntaps * cin * coutP;
+    const long total = winograd == 3 ? (long)((cin + 1) / 2) * 2 * 4 * coutP
+                       : (winograd ? (long)cdiv(cin, WN_CK) * WN_CK * coutP : (long)ntaps * cin * coutP);
     return cdiv(total, 256);
 }
 

@@ -502,9 +502,13 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
         key = (wname, "fwd", "s2w")
         upk = ctx._packed.get(key)
         if upk is None:
-            upk = torch.empty(lib().c2s_s2wino_packed_floats(Cin, CoutP), device=ctx.device, dtype=torch.float32)
-            check(lib().c2s_pack_weights_s2wino(W.data_ptr(), upk.data_ptr(), Cin, Cout, CoutP, Cin * KK, KK, _tap_array(list(range(KK))),
-                                                _stream()), "pack_weights_s2wino")
+            upk = ctx._planned(key, W.data_ptr())
+            if upk is None:
+                nfl = lib().c2s_s2wino_packed_floats(Cin, CoutP)
+                upk = torch.empty(nfl, device=ctx.device, dtype=torch.float32)
+                check(lib().c2s_pack_weights_s2wino(W.data_ptr(), upk.data_ptr(), Cin, Cout, CoutP, Cin * KK, KK,
+                                                    _tap_array(list(range(KK))), _stream()), "pack_weights_s2wino")
+                ctx.ws.pack_record[key] = (W.data_ptr(), Cin, Cout, CoutP, 16, Cin * KK, KK, 3, tuple(range(KK)), nfl)
             ctx._packed[key] = upk
         d = ConvDesc(N, C0, 0, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
         check(lib().c2s_conv4x4s2_winograd(C.byref(d), s0.data_ptr(), upk.data_ptr(), _ptr(ctx.p[bname] if bname else None),
