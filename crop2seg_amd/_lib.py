@@ -78,6 +78,10 @@ SIGNATURES = {
     "c2s_pack_weights_s2wino": (I, [P, P, I, I, I, L, L, C.POINTER(I), P]),
     "c2s_conv4x4s2_winograd_supported": (I, [C.POINTER(ConvDesc)]),
     "c2s_conv4x4s2_winograd": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P]),
+    "c2s_s2dgrad_packed_floats": (SZ, [I, I]),
+    "c2s_pack_weights_s2dgrad": (I, [P, P, I, I, I, L, L, C.POINTER(I), P]),
+    "c2s_conv4x4s2_dgrad_winograd_supported": (I, [C.POINTER(ConvDesc)]),
+    "c2s_conv4x4s2_dgrad_winograd": (I, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "c2s_bf16x3_packed_elems": (SZ, [I, I]),
     "c2s_pack_weights_bf16x3": (I, [P, P, P, I, I, I, I, L, L, C.POINTER(I), P]),
     "c2s_conv3x3_bf16x3": (I, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P]),

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libc2s_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_bf16x3.hip", "conv_xpair.hip", "conv_first.hip", "conv_winograd.hip", "conv_winograd16.hip", "conv_s2wino.hip", "conv_wgrad.hip", "norm.hip", "se.hip", "ltae.hip", "ltae_pe.hip", "aggregate.hip", "misc.hip", "metrics.hip", "io.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bf16x3.hip", "conv_xpair.hip", "conv_first.hip", "conv_winograd.hip", "conv_winograd16.hip", "conv_s2wino.hip", "conv_s2dgrad.hip", "conv_wgrad.hip", "norm.hip", "se.hip", "ltae.hip", "ltae_pe.hip", "aggregate.hip", "misc.hip", "metrics.hip", "io.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-D__HIP_PLATFORM_AMD__"]
 

@@ -563,6 +563,22 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             else:
                 assert K == 4 and S == 2 and pad == 1
                 assert Hin == 2 * Ho and Win == 2 * Wo
+                CsP = (Cs + 63) // 64 * 64
+                dw = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CsP, Hin, Win, Hin, Win, 4, 4, 2, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0, accf, radj)
+                if S2WINO and CONV_MODE == "f32" and lib().c2s_conv4x4s2_dgrad_winograd_supported(C.byref(dw)):
+                    key = (wname, "dgrad", "s2d", si)
+                    upk = ctx._packed.get(key)
+                    if upk is None:
+                        upk = torch.empty(lib().c2s_s2dgrad_packed_floats(Cout, CsP), device=ctx.device, dtype=torch.float32)
+                        check(lib().c2s_pack_weights_s2dgrad(W.data_ptr() + 4 * c_lo * KK, upk.data_ptr(), Cout, Cs, CsP, KK, Cin * KK,
+                                                             _tap_array(list(range(KK))), _stream()), "pack_weights_s2dgrad")
+                        ctx._packed[key] = upk
+                    check(lib().c2s_conv4x4s2_dgrad_winograd(C.byref(dw), g.data_ptr(), upk.data_ptr(), gin.data_ptr(), _ptr(valid),
+                                                             _stream()), "conv4x4s2_dgrad_winograd")
+                    if existing is None:
+                        tape.grads[src.data_ptr()] = gin
+                    c_lo += Cs
+                    continue
                 for py in range(2):         # one launch per output-row parity, both column parities fused
                     wd, CP = ctx.pack((wname, "dgrad", si, py), W, c_lo * KK, Cout, Cs, 8, KK, Cin * KK, _xpair_taps(py))
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Ho, Wo, Hin, Win, 2, 2, 1, 1 - py, 0, _lib.PAD_ZEROS,

@@ -172,6 +172,24 @@ int c2s_conv4x4s2_winograd(const c2s_conv_desc* d, const float* src, const float
                            const int* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Data gradient of the same 4x4 stride-2 pad-1 convolution as Winograd F(2x2,2x2) per output parity (conv_s2dgrad.hip):
+ * gx[2m+e] is a 2-tap filter over gy per parity e; one workgroup per row parity, both column parities per lane (16-byte
+ * stores).  The descriptor describes the gradient launch: C0 = gy channels (a multiple of 8, >= 24), Hin x Win = the gy plane
+ * (even, at least 32 wide and 8 high), Cout / CoutP (multiple of 64) = the input channels receiving the gradient, Hout x Wout
+ * = 2 Hin x 2 Win, dense output; reflect_adjoint = 1: the forward pass was reflect-padded -- the halo gradient is folded in
+ * by a variant 3-multiply algorithm in the border blocks (no second pass); accumulate as for c2s_conv_igemm.
+ * upk = c2s_pack_weights_s2dgrad (c2s_s2dgrad_packed_floats(C0, CoutP) floats; element (k = gy channel, c = input channel,
+ * tap) read at src[c * stride_c + k * stride_k + tap_off[ky * 4 + kx]]).
+ * Replaces: convolution_backward-input of nn.Conv2d(4, stride 2, padding 1) in DownConvBlock (conv.py:263-271).
+ * ------------------------------------------------------------------------------------------------ */
+size_t c2s_s2dgrad_packed_floats(int kc, int csP);
+int c2s_pack_weights_s2dgrad(const float* src, float* upk, int kc, int cs, int csP, long stride_c, long stride_k,
+                             const int* host_tap_off, void* stream);
+int c2s_conv4x4s2_dgrad_winograd_supported(const c2s_conv_desc* d);
+int c2s_conv4x4s2_dgrad_winograd(const c2s_conv_desc* d, const float* gy, const float* upk, float* gx, const int* valid,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Opt-in split-precision variant of the 3x3 stride-1 pad-1 convolution (forward and data gradient, same
  * descriptor as c2s_conv_igemm): every fp32 operand is split into two bf16 halves (hi + lo, 16 significant bits)
  * and each product evaluated with three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi) accumulating in fp32

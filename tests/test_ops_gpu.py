@@ -153,8 +153,9 @@ S2WINO_CASES = [
 
 @pytest.mark.parametrize("case", S2WINO_CASES)
 def test_conv4x4s2_winograd(case):
-    """The F(2x2,2x2)-over-parities kernel for the 4x4 stride-2 forward convolution (conv_s2wino.hip; C2S_S2WINO) against the
-    oracle; the backward pass of the same layer (transposed-row data gradient, direct weight gradient) is unchanged."""
+    """The F(2x2,2x2) kernels of the 4x4 stride-2 convolution (C2S_S2WINO) against the oracle: forward over the four input
+    parities (conv_s2wino.hip) and data gradient per output parity with the reflect adjoint folded in by the variant
+    3-multiply algorithm of the border blocks (conv_s2dgrad.hip); the weight gradient is the direct kernel's."""
     E, L = _engine()
     N, Cin, Cout, Hin, Win, mode = case
     g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
@@ -183,6 +184,7 @@ def test_conv4x4s2_winograd(case):
         gfull = torch.zeros(N, *ref.shape[1:])
         gfull[keep] = gout
         seed_backward(ctx, out, gfull)
+        assert ("w", "dgrad", "s2d", 0) in ctx._packed          # the data gradient ran on conv_s2dgrad.hip as well
     finally:
         E.S2WINO = old
     assert rel(ctx.tape.grads[xd.data_ptr()][keep.cuda()], x.grad[keep]) < 5e-6
