@@ -427,7 +427,7 @@ struct PackJob {
     float* dst;
     long so, sc;
     int cin, cout, coutP, ntaps;
-    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U   2: Winograd U in the 8-wave kernel's layout   3: conv_s2wino.hip's
+    int kind;            // 0: wpk[tap][cin][coutP]   1: Winograd U   2: Winograd U in the 8-wave kernel's layout   3: conv_s2wino.hip's   4: conv_s2dgrad.hip's
     int block_start;     // first block of this job
     int taps[16];
 };
@@ -463,6 +463,36 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
                 g2[a][b] = real ? jb.src[o * jb.so + c * jb.sc + jb.taps[ky * 4 + kx]] : 0.f;
             }
         float* base = jb.dst + ((((size_t)(o >> 6) * nch2 + (c >> 1)) * 2 + (c & 1)) * 4 + par) * 64 * 12 + (size_t)(o & 63) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float u0 = i == 0 ? g2[0][0] : (i == 1 ? g2[0][0] + g2[1][0] : g2[1][0]);
+            const float u1 = i == 0 ? g2[0][1] : (i == 1 ? g2[0][1] + g2[1][1] : g2[1][1]);
+            base[i * 3 + 0] = u0;
+            base[i * 3 + 1] = u0 + u1;
+            base[i * 3 + 2] = u1;
+        }
+        return;
+    }
+    if (jb.kind == 4) {          // per-parity sub-filters of the 4x4 stride-2 data gradient (conv_s2dgrad.hip); here cin = gy
+                                 // channels k, cout / coutP = input channels c: element at src[c * so + k * sc + tap]
+        const long total4 = (long)4 * jb.cin * jb.coutP;
+        if (e >= total4) return;
+        const int c = (int)(e % jb.coutP);
+        const int k = (int)((e / jb.coutP) % jb.cin);
+        const int par = (int)(e / jb.coutP / jb.cin);
+        const int ey = par >> 1, ex = par & 1;
+        const bool real = c < jb.cout;
+        float g2[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ky = (ey == 0 ? 3 : 2) - 2 * a, kx = (ex == 0 ? 3 : 2) - 2 * b;
+                g2[a][b] = real ? jb.src[c * jb.so + k * jb.sc + jb.taps[ky * 4 + kx]] : 0.f;
+            }
+        const int cblocks = jb.coutP / 64, nch8 = jb.cin / 8;
+        float* base = jb.dst + ((((size_t)(ey * cblocks + (c >> 6)) * nch8 + (k >> 3)) * 2 + ((k >> 2) & 1)) * 4 + (k & 3)) * 128 * 12 +
+                      (size_t)(ex * 64 + (c & 63)) * 12;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float u0 = i == 0 ? g2[0][0] : (i == 1 ? g2[0][0] + g2[1][0] : g2[1][0]);
@@ -537,7 +567,7 @@ extern "C" size_t c2s_pack_job_bytes(void) { return sizeof(PackJob); }
 // Fill one job record of a host-side table (the caller uploads the table once and reuses it every step)
 extern "C" int c2s_pack_job_fill(void* host_record, const float* src, float* dst, int cin, int cout, int coutP, int ntaps,
                                  long stride_o, long stride_c, int winograd, const int* host_tap_off, int block_start) {
-    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16 && winograd >= 0 && winograd <= 3,
+    C2S_REQUIRE(host_record && src && dst && host_tap_off && ntaps >= 1 && ntaps <= 16 && winograd >= 0 && winograd <= 4,
                 "pack_job_fill: bad args");
     PackJob* j = reinterpret_cast<PackJob*>(host_record);
     j->src = src; j->dst = dst; j->so = stride_o; j->sc = stride_c;
@@ -548,7 +578,7 @@ extern "C" int c2s_pack_job_fill(void* host_record, const float* src, float* dst
 
 // blocks (of 256 threads) a job needs
 extern "C" int c2s_pack_job_blocks(int cin, int coutP, int ntaps, int winograd) {
-    const long total = winograd == 3 ? (long)((cin + 1) / 2) * 2 * 4 * coutP
+    const long total = winograd == 4 ? (long)4 * cin * coutP : winograd == 3 ? (long)((cin + 1) / 2) * 2 * 4 * coutP
                        : (winograd ? (long)cdiv(cin, WN_CK) * WN_CK * coutP : (long)ntaps * cin * coutP);
     return cdiv(total, 256);
 }

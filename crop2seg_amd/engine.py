@@ -569,9 +569,15 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
                     key = (wname, "dgrad", "s2d", si)
                     upk = ctx._packed.get(key)
                     if upk is None:
-                        upk = torch.empty(lib().c2s_s2dgrad_packed_floats(Cout, CsP), device=ctx.device, dtype=torch.float32)
-                        check(lib().c2s_pack_weights_s2dgrad(W.data_ptr() + 4 * c_lo * KK, upk.data_ptr(), Cout, Cs, CsP, KK, Cin * KK,
-                                                             _tap_array(list(range(KK))), _stream()), "pack_weights_s2dgrad")
+                        src_ptr = W.data_ptr() + 4 * c_lo * KK
+                        upk = ctx._planned(key, src_ptr)
+                        if upk is None:
+                            nfl = lib().c2s_s2dgrad_packed_floats(Cout, CsP)
+                            upk = torch.empty(nfl, device=ctx.device, dtype=torch.float32)
+                            check(lib().c2s_pack_weights_s2dgrad(src_ptr, upk.data_ptr(), Cout, Cs, CsP, KK, Cin * KK,
+                                                                 _tap_array(list(range(KK))), _stream()), "pack_weights_s2dgrad")
+                            # (pack-plan record: cin = gy channels, cout = input channels, strides as passed to the pack)
+                            ctx.ws.pack_record[key] = (src_ptr, Cout, Cs, CsP, 16, KK, Cin * KK, 4, tuple(range(KK)), nfl)
                         ctx._packed[key] = upk
                     check(lib().c2s_conv4x4s2_dgrad_winograd(C.byref(dw), g.data_ptr(), upk.data_ptr(), gin.data_ptr(), _ptr(valid),
                                                              _stream()), "conv4x4s2_dgrad_winograd")

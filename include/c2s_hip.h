@@ -61,7 +61,7 @@ int c2s_pack_weights(const float* src, float* wpk, int cin, int cout, int coutP,
 /* All weight packs of a step in one launch.  The caller builds a table of job records once (host memory, record size
  * c2s_pack_job_bytes(), filled by c2s_pack_job_fill: winograd = 0 plain tap-major pack as c2s_pack_weights, 1 the Winograd
  * transform of c2s_pack_weights_winograd, 2 the same in the layout of c2s_pack_weights_winograd16, 3 the parity sub-filters
- * of c2s_pack_weights_s2wino), uploads it, and calls c2s_pack_batch(device_table, njobs, total_blocks) every step;
+ * of c2s_pack_weights_s2wino, 4 those of c2s_pack_weights_s2dgrad with cin = gy channels, cout = input channels), uploads it, and calls c2s_pack_batch(device_table, njobs, total_blocks) every step;
  * block_start of job i = sum of c2s_pack_job_blocks over the jobs before it. */
 size_t c2s_pack_job_bytes(void);
 int c2s_pack_job_fill(void* host_record, const float* src, float* dst, int cin, int cout, int coutP, int ntaps,
