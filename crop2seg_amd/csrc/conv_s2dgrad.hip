@@ -395,14 +395,15 @@ extern "C" int c2s_pack_weights_s2dgrad(const float* src, float* upk, int kc, in
 extern "C" int c2s_conv4x4s2_dgrad_winograd_supported(const c2s_conv_desc* d) {
     return d && d->KH == 4 && d->KW == 4 && d->S == 2 && d->pad_y == 1 && d->pad_x == 1 && d->C1 == 0 && d->C0 % 8 == 0 &&
            d->C0 >= 24 && d->Hout == 2 * d->Hin && d->Wout == 2 * d->Win && d->Hin % 2 == 0 && d->Win % 2 == 0 &&
-           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0;
+           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->N <= 32768;
 }
 
 extern "C" int c2s_conv4x4s2_dgrad_winograd(const c2s_conv_desc* d, const float* gy, const float* upk, float* gx,
                                             const int* valid, void* stream) {
     C2S_REQUIRE(d && gy && upk && gx, "conv4x4s2_dgrad_winograd: null pointer");
     C2S_REQUIRE(c2s_conv4x4s2_dgrad_winograd_supported(d), "conv4x4s2_dgrad_winograd: data gradient of a 4x4 stride 2 pad 1 convolution, gy channels a multiple of 8 (>= 24), even gy planes at least 32 wide and 8 high, CoutP %% 64");
-    C2S_REQUIRE(d->N > 0 && d->N <= 65536 && d->Cout > 0 && d->CoutP >= d->Cout, "conv4x4s2_dgrad_winograd: bad N / channels");
+    C2S_REQUIRE(d->N > 0 && d->N <= 32768 && d->Cout > 0 && d->CoutP >= d->Cout,
+                "conv4x4s2_dgrad_winograd: bad N / channels (at most 32768 frames: their flag bits share the last 4 KB of LDS)");
     C2S_REQUIRE(d->OutH == d->Hout && d->OutW == d->Wout && d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0,
                 "conv4x4s2_dgrad_winograd: dense output only");
     C2S_REQUIRE((long)d->C0 * d->Hin * d->Win * 4 < 0x7FFF0000L && (long)d->CoutP * d->Hout * d->Wout * 4 < 0x7FFF0000L,

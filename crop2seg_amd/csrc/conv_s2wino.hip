@@ -371,7 +371,7 @@ extern "C" int c2s_pack_weights_s2wino(const float* src, float* upk, int cin, in
 extern "C" int c2s_conv4x4s2_winograd_supported(const c2s_conv_desc* d) {
     return d && d->KH == 4 && d->KW == 4 && d->S == 2 && d->pad_y == 1 && d->pad_x == 1 && d->C1 == 0 && d->C0 % 2 == 0 &&
            d->C0 >= 8 && d->Hin == 2 * d->Hout && d->Win == 2 * d->Wout && d->Hout % 2 == 0 && d->Wout % 2 == 0 &&
-           d->Wout >= 32 && d->Hout >= 8 && d->CoutP % 64 == 0 && d->reflect_adjoint == 0;
+           d->Wout >= 32 && d->Hout >= 8 && d->CoutP % 64 == 0 && d->reflect_adjoint == 0 && d->N <= 65536;
 }
 
 extern "C" int c2s_conv4x4s2_winograd(const c2s_conv_desc* d, const float* src, const float* upk, const float* bias,

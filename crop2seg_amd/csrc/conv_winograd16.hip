@@ -485,7 +485,8 @@ extern "C" int c2s_pack_weights_winograd16(const float* src, float* upk, int cin
 
 extern "C" int c2s_conv3x3_winograd16_supported(const c2s_conv_desc* d) {
     return d && d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Hin % 2 == 0 && d->Win % 2 == 0 &&
-           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 3 * W16_CK && (d->C1 == 0 || d->C0 % W16_CK == 0);
+           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 3 * W16_CK && (d->C1 == 0 || d->C0 % W16_CK == 0) &&
+           d->N <= 65536;
 }
 
 extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
