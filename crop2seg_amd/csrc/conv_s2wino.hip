@@ -143,15 +143,20 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
     // requests (uniform across the workgroup): raw planes three chunks ahead, U two ahead (see conv_winograd16.hip)
     bool u_ok = false, young_raw = false;
     int u_k = 0;
+#ifndef C2S_S2W_DIAG
+#define C2S_S2W_DIAG 0          // diagnostic builds: 1 = no U requests after the first chunks, 2 = no raw requests, 3 = neither
+#endif
+    int diag_n = 0;
     auto stage_next_u = [&](int h0) {
-        if (u_ok) stage_u(u_k, h0);
+        if (u_ok && (!(C2S_S2W_DIAG & 1) || diag_n < 3)) stage_u(u_k, h0);
     };
     auto stage_next_raw = [&](int slot) {
         u_ok = stile < ntotal;
         u_k = sk;
         young_raw = u_ok;
         if (!u_ok) return;
-        stage_raw(sk, slot);
+        if (!(C2S_S2W_DIAG & 2) || diag_n < 3) stage_raw(sk, slot);
+        ++diag_n;
         if (++sk == K) {                               // once per multiplied tile (K >= 4), at its chunk K - 4
             sk = 0;
             stile = next_valid(stile + gridDim.x);
