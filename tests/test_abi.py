@@ -56,6 +56,45 @@ def test_smallcin_dispatch_predicate_without_gpu():
     assert rc == -1 and b"smallcin" in L.c2s_last_error()
 
 
+def test_winograd_family_predicates_without_gpu():
+    """Host-side predicates and argument checks of the round-3 Winograd kernels (8-wave F(2x2,3x3); F(2x2,2x2) forward and
+    data gradient of the 4x4 stride-2 convolution): what they take, what the engine must route elsewhere."""
+    from crop2seg_amd import _lib
+    L = _lib.lib()
+
+    def d3(n=4, c0=64, c1=0, cout=64, h=128, w=128):
+        return _lib.ConvDesc(n, c0, c1, h, w, cout, (cout + 63) // 64 * 64, h, w, h, w, 3, 3, 1, 1, 1, _lib.PAD_REFLECT, 1, 1, 0, 0, 0)
+
+    assert L.c2s_conv3x3_winograd16_supported(ctypes.byref(d3())) == 1
+    assert L.c2s_conv3x3_winograd16_supported(ctypes.byref(d3(c0=32, c1=64, cout=72, h=12, w=40))) == 1
+    for bad in (d3(w=16), d3(h=4), d3(c0=24), d3(c0=36, c1=8), d3(n=70000)):      # narrow / low planes, < 4 chunks, ragged first source
+        assert L.c2s_conv3x3_winograd16_supported(ctypes.byref(bad)) == 0
+    assert L.c2s_conv3x3_winograd16(ctypes.byref(d3(w=16)), 16, None, 16, None, 16, None, None) == -1
+    assert b"winograd16" in L.c2s_last_error()
+
+    def d4(n=4, cin=64, cout=64, hin=128, win=128, c1=0):
+        return _lib.ConvDesc(n, cin, c1, hin, win, cout, (cout + 63) // 64 * 64, hin // 2, win // 2, hin // 2, win // 2, 4, 4, 2, 1, 1,
+                             _lib.PAD_REFLECT, 1, 1, 0, 0, 0)
+
+    assert L.c2s_conv4x4s2_winograd_supported(ctypes.byref(d4())) == 1
+    assert L.c2s_conv4x4s2_winograd_supported(ctypes.byref(d4(cin=8, cout=72, hin=24, win=80))) == 1
+    for bad in (d4(cin=7), d4(cin=6), d4(win=32), d4(hin=8), d4(c1=8)):           # odd / too few channels, output plane < 32 wide or < 8 high
+        assert L.c2s_conv4x4s2_winograd_supported(ctypes.byref(bad)) == 0
+    assert L.c2s_conv4x4s2_winograd(ctypes.byref(d4(win=32)), 16, 16, None, 16, None, None) == -1
+
+    def dg(n=4, kc=64, cs=64, ho=64, wo=64, radj=1):                               # the gradient launch: gy [kc, ho, wo] -> gx [cs, 2 ho, 2 wo]
+        return _lib.ConvDesc(n, kc, 0, ho, wo, cs, (cs + 63) // 64 * 64, 2 * ho, 2 * wo, 2 * ho, 2 * wo, 4, 4, 2, 1, 1, _lib.PAD_ZEROS,
+                             1, 1, 0, 0, 0, radj)
+
+    assert L.c2s_conv4x4s2_dgrad_winograd_supported(ctypes.byref(dg())) == 1
+    assert L.c2s_conv4x4s2_dgrad_winograd_supported(ctypes.byref(dg(kc=72, cs=10, ho=12, wo=40, radj=0))) == 1
+    for bad in (dg(kc=16), dg(kc=60), dg(wo=16), dg(ho=6), dg(n=40000)):
+        assert L.c2s_conv4x4s2_dgrad_winograd_supported(ctypes.byref(bad)) == 0
+    assert L.c2s_conv4x4s2_dgrad_winograd(ctypes.byref(dg(kc=16)), 16, 16, 16, None, None) == -1
+    assert L.c2s_s2wino_packed_floats(64, 64) == 32 * 2 * 4 * 64 * 12 and L.c2s_s2dgrad_packed_floats(64, 64) == 4 * 64 * 64 * 12
+    assert L.c2s_winograd16_packed_floats(64, 64) == 8 * 8 * 64 * 20
+
+
 @pytest.mark.parametrize("name", ["utae_eval_pad_wi", "timeunet_eval_pad_wi", "wtae_eval_pad_wi"])
 def test_state_dict_layout_matches_reference(goldens, name):
     import crop2seg_amd as C2S
