@@ -29,23 +29,38 @@ def chain(xc, ctx):
     return E.norm_act(ctx, h, "n2", L.NORM_GROUP, 4, True, None, None)
 
 
-def run(nchunks):
-    ctx = E.Ctx(p, {}, None, ws, True, None)
+grads = {k: torch.zeros_like(v) for k, v in p.items()}
+gfull = torch.randn(N, Cc, H, H, device=dev)
+
+
+def run(nchunks, backward=False):
     outs = []
     step = N // nchunks
-    for i in range(nchunks):
-        outs.append(chain(x[i * step:(i + 1) * step], ctx))
+    if not backward:
+        ctx = E.Ctx(p, {}, None, ws, True, None)
+        for i in range(nchunks):
+            outs.append(chain(x[i * step:(i + 1) * step], ctx))
+        return outs
+    gw = set()
+    for i in range(nchunks):          # forward + backward of one chunk at a time (weight gradients accumulate over the chunks)
+        ctx = E.Ctx(p, {}, grads, ws, True, E.Tape())
+        ctx._gwritten = gw
+        xc = x[i * step:(i + 1) * step]
+        y = chain(xc, ctx)
+        ctx.tape.grads[y.data_ptr()] = gfull[i * step:(i + 1) * step]
+        ctx.tape.backward()
     return outs
 
 
+BWD = "--bwd" in sys.argv
 for nchunks in (1, 2, 4, 8):
-    run(nchunks)
+    run(nchunks, BWD)
     torch.cuda.synchronize()
     ts = []
     for _ in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        run(nchunks)
+        run(nchunks, BWD)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
