@@ -309,16 +309,27 @@ __global__ __launch_bounds__(512, 1) void conv_s2dgrad_kernel(S2dParams p) {
                     }
                 }
                 const int so = (16 * mt + 2 * h) * HWin * 4;
+                f32x4 v[2][2];                                              // [channel of the pair][output row]
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {                               // channel of the pair
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {                           // output row
-                        f32x4 v = {Y[0][i][0][j], Y[1][i][0][j], Y[0][i][1][j], Y[1][i][1][j]};
-                        const int vo = i == 0 ? vo0 : vo1;
-                        if (p.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, vo, so + j * HWin * 4, 0));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so + j * HWin * 4, 0);
-                    }
+                    for (int i = 0; i < 2; ++i) v[j][i] = (f32x4){Y[0][i][0][j], Y[1][i][0][j], Y[0][i][1][j], Y[1][i][1][j]};
+                if (p.accumulate) {                                         // the four reads in flight before the first add
+                    u32x4 o[2][2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) o[j][i] = __builtin_amdgcn_raw_buffer_load_b128(ro, i == 0 ? vo0 : vo1, so + j * HWin * 4, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) v[j][i] += __builtin_bit_cast(f32x4, o[j][i]);
                 }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j][i]), ro, i == 0 ? vo0 : vo1, so + j * HWin * 4, 0);
             }
         }
         if (stile >= ntotal) break;
