@@ -13,7 +13,8 @@
 // transforms the 3x3 patch of its parity plane; A operand = U[p][(c, parity)][o], 9 points padded to 12 floats (three
 // conflict-free ds_read_b128).  A chunk is two input channels: 24 KB of U (two half slabs of a ring of five) and the eight
 // parity planes of the 8 x 32 output tile (9 x 33 each, gathered by buffer_load_dword ... lds with reflected / stride-2 source
-// addresses; ring of four).  Wave w: output channels 32 (w & 1) .., block row w >> 1; accumulators acc[9][2] of 16x16.
+// addresses; ring of four).  Wave w: output channels 32 (w & 1) .., block rows 2 (w >> 1), 2 (w >> 1) + 1 (an A operand
+// serves two block rows: half the U traffic per MFMA of a one-row wave); accumulators acc[9][2][2] of 16x16.
 //
 // Reference call sites replaced: nn.Conv2d(4, stride 2, padding 1, reflect) of DownConvBlock (src/backbones/conv.py:263-271)
 // for layers with an even number (>= 8) of input channels on output planes at least 32 wide (the engine keeps
@@ -38,12 +39,12 @@ constexpr int S2_UP = 12;                            // floats per (c, parity, o
 constexpr int S2_UHALF = 4 * 64 * S2_UP;             // one k-step (one input channel, four parities): 3,072 floats = 12 KB
 constexpr int S2_USLAB = 2 * S2_UHALF;               // a chunk of two input channels: 24 KB
 constexpr int S2_URING = 5 * S2_UHALF;               // 60 KB
-constexpr int S2_BR = 4, S2_BC = 16;                 // blocks per tile: 4 rows x 16 columns = 8 x 32 output pixels
-constexpr int S2_RR = 2 * S2_BR + 1, S2_RC = 34;     // a parity plane of the tile: 9 rows x 33 columns, row pitch 34
-constexpr int S2_PLANE = S2_RR * S2_RC;              // 306
-constexpr int S2_XP = 352;                           // LDS pitch per plane (= 32 mod 64 banks)
-constexpr int S2_MAXE = 6;                           // raw-tile LDS-DMA pieces per thread (one float each)
-constexpr int S2_XS = S2_MAXE * 512;                 // 3,072 floats: 8 planes x 352 and a zero-filled tail
+constexpr int S2_BR = 8, S2_BC = 16;                 // blocks per tile: 8 rows x 16 columns = 16 x 32 output pixels
+constexpr int S2_RR = 2 * S2_BR + 1, S2_RC = 34;     // a parity plane of the tile: 17 rows x 33 columns, row pitch 34
+constexpr int S2_PLANE = S2_RR * S2_RC;              // 578
+constexpr int S2_XP = 608;                           // LDS pitch per plane (= 32 mod 64 banks)
+constexpr int S2_MAXE = 10;                          // raw-tile LDS-DMA pieces per thread (one float each)
+constexpr int S2_XS = S2_MAXE * 512;                 // 5,120 floats: 8 planes x 608 and a zero-filled tail
 constexpr int S2_XSLOTS = 4;
 constexpr int S2_LDS_FLOATS = S2_URING + S2_XSLOTS * S2_XS + 64;     // + the bias of the 64 channels (+ frame flag bits)
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
     float* lbias = lds + S2_URING + S2_XSLOTS * S2_XS;
     if (tid < 64) lbias[tid] = (p.bias != nullptr && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
     __syncthreads();
-    auto next_valid = [&](int tt) {
+    auto next_valid = [&](int tt) __attribute__((always_inline)) {
         while (tt < ntotal) {
             const int f = tt / p.tiles;
             if ((lvalid[f >> 5] >> (f & 31)) & 1u) break;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
         }
         return tt;
     };
-    auto tile_origin = [&](int tt, int& n, int& oy0, int& ox0) {
+    auto tile_origin = [&](int tt, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
         n = tt / p.tiles;
         const int ti = tt - n * p.tiles;
         const int tyi = ti / p.tiles_x, txi = ti - tyi * p.tiles_x;
@@ -96,10 +97,10 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
     // (r, q) is the input pixel (2 (oy0 + r) - py, 2 (ox0 + q) - px)
     int goff[S2_MAXE];
     __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, 0, 0x00020000);
-    auto begin_staging = [&](int tt) {
+    auto begin_staging = [&](int tt) __attribute__((always_inline)) {
         int n, oy0, ox0;
         tile_origin(tt, n, oy0, ox0);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < S2_MAXE; ++i) {
             const int e = tid + i * 512;
             const int pc = e / S2_XP, rem = e - pc * S2_XP;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
     };
     // U chunk k -> half slabs h0, h0 + 1 (mod 5): 24 KB contiguous in global memory, three 16-byte pieces per thread; piece 1
     // straddles the halves at a wave boundary (waves 0-3 | 4-7)
-    auto stage_u = [&](int k, int h0) {
+    auto stage_u = [&](int k, int h0) __attribute__((always_inline)) {
         const int h1 = h0 == 4 ? 0 : h0 + 1;
         const C2S_AS1 char* g = (const C2S_AS1 char*)p.upk + ((size_t)blockIdx.y * K + k) * (S2_USLAB * 4);
         float* d0 = lds + h0 * S2_UHALF + w * 256;
@@ -127,10 +128,10 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
             __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 8192 + (unsigned)(tid * 16)), (C2S_AS3 void*)(dst + i * 2048), 16, 0, 0);
         }
     };
-    auto stage_raw = [&](int k, int slot) {
+    auto stage_raw = [&](int k, int slot) __attribute__((always_inline)) {
         const int chan0 = 2 * k * HWin * 4;                      // scalar offset of the request
         float* Xd = lds + S2_URING + slot * S2_XS + w * 64;
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < S2_MAXE; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (C2S_AS3 void*)(Xd + i * 512), 4, goff[i], chan0, 0, 0);
     };
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
 #define C2S_S2W_DIAG 0          // diagnostic builds: 1 = no U requests after the first chunks, 2 = no raw requests, 3 = neither
 #endif
     int diag_n = 0;
-    auto stage_next_u = [&](int h0) {
+    auto stage_next_u = [&](int h0) __attribute__((always_inline)) {
         if (u_ok && (!(C2S_S2W_DIAG & 1) || diag_n < 3)) stage_u(u_k, h0);
     };
-    auto stage_next_raw = [&](int slot) {
+    auto stage_next_raw = [&](int slot) __attribute__((always_inline)) {
         u_ok = stile < ntotal;
         u_k = sk;
         young_raw = u_ok;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
 
     // LDS offsets of this lane's operands
     const int aoff = (kq * 64 + 32 * ch + t) * S2_UP;                          // in a half slab; + mt * 16 * UP
-    const int boff = S2_URING + kq * S2_XP + (2 * brow) * S2_RC + 2 * t;       // in a raw slot; + s * 4 * XP + r * RC
+    const int boff = S2_URING + kq * S2_XP + (4 * brow) * S2_RC + 2 * t;       // in a raw slot (block row 2 brow); + s * 4 * XP + (2 br + r) * RC
     auto load_a = [&](const float* ab, int mt, float (&a)[12]) {                // (9 used)
 #pragma unroll
         for (int q4 = 0; q4 < 3; ++q4) {
@@ -180,18 +181,19 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
     };
     int boff0 = boff, boff1 = boff + 4 * S2_XP;        // (the two k-steps; opaque: the row offsets stay ds_read2 immediates)
     asm volatile("" : "+v"(boff0), "+v"(boff1));
-    auto load_d = [&](const float* bufp, int s, f32x2 (&dl)[3], f32x2 (&dh)[3]) {      // patch rows as (cols 0,1), (cols 2,3)
+    // the patches of the wave's two block rows share their middle row: five rows as (cols 0,1), (cols 2,3)
+    auto load_d = [&](const float* bufp, int s, f32x2 (&dl)[5], f32x2 (&dh)[5]) {
         const float* bb = bufp + (s ? boff1 : boff0);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 5; ++r) {
             dl[r] = *reinterpret_cast<const f32x2*>(bb + r * S2_RC);
             dh[r] = *reinterpret_cast<const f32x2*>(bb + r * S2_RC + 2);
         }
     };
     // V = Bt d B of the 3x3 patch (point p = 3 xi + nu)
-    auto transform = [&](const f32x2 (&dl)[3], const f32x2 (&dh)[3], float (&V)[9]) {
-        const f32x2 tl[3] = {dl[0] - dl[1], dl[1], dl[2] - dl[1]};
-        const float th[3] = {dh[0][0] - dh[1][0], dh[1][0], dh[2][0] - dh[1][0]};
+    auto transform = [&](f32x2 l0, f32x2 l1, f32x2 l2, f32x2 h0, f32x2 h1, f32x2 h2, float (&V)[9]) {
+        const f32x2 tl[3] = {l0 - l1, l1, l2 - l1};
+        const float th[3] = {h0[0] - h1[0], h1[0], h2[0] - h1[0]};
 #pragma unroll
         for (int xi = 0; xi < 3; ++xi) {
             V[3 * xi] = tl[xi][0] - tl[xi][1];
@@ -199,23 +201,23 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
             V[3 * xi + 2] = th[xi] - tl[xi][1];
         }
     };
-    f32x4 acc[9][2];
+    f32x4 acc[9][2][2];                                // [point][channel group][block row]
     // first = the first k-step of a tile: accumulators start at 0 (inline constant), those of point (1,1) at the bias
     // (At e11 A = [[1,1],[1,1]])
-    auto mma = [&](const float (&a)[12], const float (&V)[9], int mt, bool first) {
+    auto mma = [&](const float (&a)[12], const float (&V)[9], int mt, int br, bool first) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             if (first) {
                 const f32x4 c0 = q == 4 ? *reinterpret_cast<const f32x4*>(lbias + 32 * ch + 16 * mt + 4 * kq) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], c0, 0, 0, 0);
+                acc[q][mt][br] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], c0, 0, 0, 0);
             } else {
-                acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], acc[q][mt], 0, 0, 0);
+                acc[q][mt][br] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], V[q], acc[q][mt][br], 0, 0, 0);
             }
         }
     };
 
-    float a0[12], a1[12], V[9];
-    f32x2 dl[3], dh[3], el[3], eh[3];
+    float a0[12], a1[12], V0[9], V1[9];
+    f32x2 dl[5], dh[5];
     const int cof = co0 + 32 * ch + 4 * kq;            // this lane's output channels: cof + 16 mt + r (D rows 4 kq + r)
     __syncthreads();                                  // (drains the first requests: vmcnt(0))
     load_a(lds + aoff, 0, a0);
@@ -223,40 +225,37 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
     while (true) {
         int n, oy0, ox0;
         tile_origin(tile, n, oy0, ox0);
-        // one chunk = two k-steps (input channels) x two channel groups; schedule as in conv_winograd16.hip
-        auto chunk = [&](bool first) {
+        // one k-step (one input channel): four half-steps (channel group, block row) of 9 MFMAs; the A operand of a channel
+        // group is read one group ahead; the next k-step's patch rows are read once both transforms have consumed the current
+        auto kstep = [&](const float* A, const float* Anext, const float* Xnext, int snext, bool first) __attribute__((always_inline)) {
+            load_a(A, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            transform(dl[0], dl[1], dl[2], dh[0], dh[1], dh[2], V0);
+            transform(dl[2], dl[3], dl[4], dh[2], dh[3], dh[4], V1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_d(Xnext, snext, dl, dh);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, V0, 0, 0, first);
+            mma(a0, V1, 0, 1, first);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(Anext, 0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, V0, 1, 0, first);
+            mma(a1, V1, 1, 1, first);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto chunk = [&](bool first) __attribute__((always_inline)) {
             const int u1 = u0 == 4 ? 0 : u0 + 1, u2 = u1 == 4 ? 0 : u1 + 1;
-            const float* xb = lds + rc * S2_XS;
-            load_a(lds + u0 * S2_UHALF + aoff, 1, a1);
-            __builtin_amdgcn_sched_barrier(0);
-            transform(dl, dh, V);
-            __builtin_amdgcn_sched_barrier(0);
-            load_d(xb, 1, el, eh);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, V, 0, first);
-            __builtin_amdgcn_sched_barrier(0);
-            load_a(lds + u1 * S2_UHALF + aoff, 0, a0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, V, 1, first);
-            __builtin_amdgcn_sched_barrier(0);
-            // everyone's requests for the NEXT chunk have landed; the six youngest (raw pieces of the chunk after next) may
-            // stay in flight -- loads complete in order
-            if (young_raw) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+            kstep(lds + u0 * S2_UHALF + aoff, lds + u1 * S2_UHALF + aoff, lds + rc * S2_XS, 1, first);
+            // everyone's requests for the NEXT chunk have landed; the youngest raw pieces (chunk after next) may stay in flight
+            if (young_raw) __builtin_amdgcn_s_waitcnt(0x0F7A);      // vmcnt(10)
             else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stage_next_u(u0 == 0 ? 4 : u0 - 1);
             stage_next_raw((rc + 3) & 3);
-            load_a(lds + u1 * S2_UHALF + aoff, 1, a1);
-            __builtin_amdgcn_sched_barrier(0);
-            transform(el, eh, V);
-            mma(a0, V, 0, false);
-            __builtin_amdgcn_sched_barrier(0);
-            load_a(lds + u2 * S2_UHALF + aoff, 0, a0);                   // (after the last chunk of the last tile: stale, unused)
-            load_d(lds + ((rc + 1) & 3) * S2_XS, 0, dl, dh);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, V, 1, false);
-            __builtin_amdgcn_sched_barrier(0);
+            // (after the last chunk of the last tile the tail reads are stale and unused)
+            kstep(lds + u1 * S2_UHALF + aoff, lds + u2 * S2_UHALF + aoff, lds + ((rc + 1) & 3) * S2_XS, 0, false);
             u0 = u2;
             rc = (rc + 1) & 3;
         };
@@ -264,9 +263,12 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
         for (int k = 1; k < K; ++k) chunk(false);
         // ---- epilogue: At M A on channel pairs; P[xi][0] = M[xi][0] + M[xi][1], P[xi][1] = M[xi][1] + M[xi][2];
         // Y[0][j] = P[0][j] + P[1][j], Y[1][j] = P[1][j] + P[2][j]; buffer stores as in conv_winograd16.hip
-        const int oy = oy0 + 2 * brow, ox = ox0 + 2 * t;
+        const int ox = ox0 + 2 * t;
         const __amdgpu_buffer_rsrc_t ro =
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)n * p.Cout * HWo), 0, p.Cout * HWo * 4, 0x00020000);
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+        const int oy = oy0 + 2 * (2 * brow + br);
         const bool in0 = ox < p.W && oy < p.H, in1 = in0 && oy + 1 < p.H;
         const int vo0 = in0 ? (cof * HWo + oy * p.W + ox) * 4 : 0x7FFF0000;
         const int vo1 = in1 ? vo0 + p.W * 4 : 0x7FFF0000;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
                 for (int xi = 0; xi < 3; ++xi) {
                     f32x2 m[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) m[j] = (f32x2){acc[3 * xi + j][mt][2 * h], acc[3 * xi + j][mt][2 * h + 1]};
+                    for (int j = 0; j < 3; ++j) m[j] = (f32x2){acc[3 * xi + j][mt][br][2 * h], acc[3 * xi + j][mt][br][2 * h + 1]};
                     P0[xi] = m[0] + m[1];
                     P1[xi] = m[1] + m[2];
                 }
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2wino_kernel(S2wParams p) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y[j][1]), ro, vo1, so + j * HWo * 4, 0);
                 }
             }
+        }
         }
         if (stile >= ntotal) break;
         tile = stile;
