@@ -751,29 +751,42 @@ struct TapTable {
     int off[16];
 };
 
+// Slice sum of one output element, shared by the per-layer and the batched kernel.  FOUR lanes per element (a launch has only
+// tens of thousands of elements and a thread-per-element loop over hundreds of slices 100+ KB apart is a chain of memory round
+// trips): lane q of a quad sums the slices k = q (mod 4) with 4 independent partial sums (loads in flight), the quad
+// combines in a fixed order -- bitwise reproducible.
+__device__ __forceinline__ float slice_sum4(const float* __restrict__ s, size_t stride, int nslices, int q) {
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = q;
+    for (; k + 12 < nslices; k += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part[u] += s[(size_t)(k + 4 * u) * stride];
+    }
+    for (int u = 0; k < nslices; k += 4, ++u) part[u] += s[(size_t)k * stride];
+    float acc = (part[0] + part[1]) + (part[2] + part[3]);
+    acc += __shfl_xor(acc, 1, 64);          // (q, q^1), then (pair, pair^2): the same tree in every lane of the quad
+    acc += __shfl_xor(acc, 2, 64);
+    return acc;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst, int nslices, int NT,
                                     int Cin, int Cout, int CinP, int CoutB, long so, long sc, TapTable tt,
                                     int accumulate) {
     const long total = (long)NT * Cin * Cout;
-    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int o = (int)(e % Cout);
-    const long tc = e / Cout;
+    const long t4 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long e = t4 >> 2;
+    const int q = (int)(t4 & 3);
+    const bool live = e < total;
+    const long ee = live ? e : total - 1;             // (whole quads stay converged for the shuffles)
+    const int o = (int)(ee % Cout);
+    const long tc = ee / Cout;
     const int c = (int)(tc % Cin), t = (int)(tc / Cin);
     const size_t stride = (size_t)NT * CinP * CoutB;
-    const float* s = slabs + ((size_t)t * CinP + c) * CoutB + o;
-    // 8 independent partial sums keep 8 loads in flight (the slices are 100+ KB apart: latency-bound otherwise);
-    // the combination order is fixed, so the result stays bitwise reproducible
-    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= nslices; k += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) part[u] += s[(size_t)(k + u) * stride];
+    const float acc = slice_sum4(slabs + ((size_t)t * CinP + c) * CoutB + o, stride, nslices, q);
+    if (live && q == 0) {
+        float* d = dst + o * so + c * sc + tt.off[t];
+        *d = accumulate ? *d + acc : acc;
     }
-    for (int u = 0; k < nslices; ++k, ++u) part[u] += s[(size_t)k * stride];
-    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-    float* d = dst + o * so + c * sc + tt.off[t];
-    *d = accumulate ? *d + acc : acc;
 }
 
 void geometry(const c2s_wgrad_desc* d, int TP, int* log2pc, int* tiles_x, int* tiles_y) {
@@ -915,23 +928,20 @@ __global__ void wgrad_reduce_batch_kernel(const ReduceJob* __restrict__ jobs, in
     while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;      // a few dozen jobs: linear scan
     const ReduceJob& jb = jobs[j];
     const long total = (long)jb.NT * jb.Cin * jb.Cout;
-    const long e = (long)(blockIdx.x - jb.block_start) * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int o = (int)(e % jb.Cout);
-    const long tc = e / jb.Cout;
+    const long t4 = (long)(blockIdx.x - jb.block_start) * blockDim.x + threadIdx.x;
+    const long e = t4 >> 2;
+    const int q = (int)(t4 & 3);
+    const bool live = e < total;
+    const long ee = live ? e : total - 1;
+    const int o = (int)(ee % jb.Cout);
+    const long tc = ee / jb.Cout;
     const int c = (int)(tc % jb.Cin), t = (int)(tc / jb.Cin);
     const size_t stride = (size_t)jb.NT * jb.CinP * jb.CoutB;
-    const float* s = jb.slabs + ((size_t)t * jb.CinP + c) * jb.CoutB + o;
-    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // same order of additions as wgrad_reduce_kernel
-    int k = 0;
-    for (; k + 8 <= jb.nslices; k += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) part[u] += s[(size_t)(k + u) * stride];
+    const float acc = slice_sum4(jb.slabs + ((size_t)t * jb.CinP + c) * jb.CoutB + o, stride, jb.nslices, q);   // (= wgrad_reduce_kernel)
+    if (live && q == 0) {
+        float* d = jb.dst + o * jb.so + c * jb.sc + jb.taps[t];
+        *d = jb.accumulate ? *d + acc : acc;
     }
-    for (int u = 0; k < jb.nslices; ++k, ++u) part[u] += s[(size_t)k * stride];
-    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-    float* d = jb.dst + o * jb.so + c * jb.sc + jb.taps[t];
-    *d = jb.accumulate ? *d + acc : acc;
 }
 }  // namespace
 
@@ -939,7 +949,7 @@ extern "C" size_t c2s_wgrad_reduce_job_bytes(void) { return sizeof(ReduceJob); }
 
 extern "C" int c2s_wgrad_reduce_job_blocks(const c2s_wgrad_desc* d) {
     if (int rc = check(d)) return rc;
-    return cdiv((long)d->KH * d->KW * (d->C0 + d->C1) * d->Cout, 256);
+    return cdiv((long)4 * d->KH * d->KW * (d->C0 + d->C1) * d->Cout, 256);      // four lanes per element
 }
 
 extern "C" int c2s_wgrad_reduce_job_fill(void* host_record, const c2s_wgrad_desc* d, const float* slabs, float* dst,
@@ -973,7 +983,7 @@ extern "C" int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, flo
     TapTable tt;
     for (int i = 0; i < 16; ++i) tt.off[i] = i < NT ? host_tap_off[i] : 0;
     const long total = (long)NT * Cin * d->Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, slabs, dst,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(4 * total, 256)), dim3(256), 0, (hipStream_t)stream, slabs, dst,
                        d->nslices, NT, Cin, d->Cout, cdiv(Cin, 32) * 32, cdiv(d->Cout, 64) * 64, stride_o, stride_c, tt,
                        accumulate);
     C2S_CHECK_LAUNCH("wgrad_reduce");
