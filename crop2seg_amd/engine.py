@@ -360,7 +360,7 @@ CONV_MODE = _os.environ.get("C2S_CONV_MODE", "f32")
 assert CONV_MODE in ("f32", "bf16x3"), CONV_MODE
 # C2S_REDUCE_BATCH=1: the split-K slice sums of all weight gradients of a backward pass in one launch at its end (one slab
 # buffer per layer) instead of one launch per layer right behind its weight-gradient kernel.  Measured neutral on the eager
-# two-stream step (11.70 vs 11.71 ms), -0.2 ms under hipGraph capture (12.3 -> 12.1 ms): off by default.
+# two-stream step (11.70 vs 11.71 ms), -0.2 ms under hipGraph capture: off by default, switched on by TrainStep.capture().
 REDUCE_BATCH = _os.environ.get("C2S_REDUCE_BATCH", "0") != "0"
 # fp32 Winograd F(2x2,3x3) for the wide 3x3 layers (forward + data gradient); C2S_WINOGRAD=0 keeps the direct kernel.
 WINOGRAD = _os.environ.get("C2S_WINOGRAD", "1") != "0"

@@ -195,19 +195,25 @@ class TrainStep:
         drop = self._fresh_dropout()
         drop.seed_dev = self.seed_dev
         saved = {k: v.clone() for k, v in self.model.named_buffers()}     # the warm-up pass must not count as a step
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                       # warm-up on the side stream: lazy one-time initialisation
-            self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)   # (function attributes, workspaces)
-        torch.cuda.current_stream().wait_stream(side)
-        for k, v in self.model.named_buffers():
-            v.copy_(saved[k])
-        torch.cuda.synchronize()
-        scale = 1.0 / self.dp.world if self.dp is not None else 1.0
-        self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb):
-            self.seed_dev.add_(1)
-            self.static_loss, self.static_logits = self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)
+        # the captured step runs on one stream: all slice sums of the weight gradients go into ONE launch at its end
+        # (engine.REDUCE_BATCH; same order of additions); the warm-up pass below builds the job table the capture reuses
+        batch0, E.REDUCE_BATCH = E.REDUCE_BATCH, True
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # warm-up on the side stream: lazy one-time initialisation
+                self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)   # (function attributes, workspaces)
+            torch.cuda.current_stream().wait_stream(side)
+            for k, v in self.model.named_buffers():
+                v.copy_(saved[k])
+            torch.cuda.synchronize()
+            scale = 1.0 / self.dp.world if self.dp is not None else 1.0
+            self.graph_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fb):
+                self.seed_dev.add_(1)
+                self.static_loss, self.static_logits = self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)
+        finally:
+            E.REDUCE_BATCH = batch0
         self.graph_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_opt):
             self.step_dev.add_(1)
