@@ -164,8 +164,9 @@ def test_full_size_train_properties(cid, model, B, T, H, lengths):
 @pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("cid,model,B,T,H,lengths", FULL[:3], ids=[f[0] for f in FULL[:3]])
 def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
-    """The Winograd F(2x2,3x3) kernels (forward, data gradient, weight gradient) and the direct implicit-GEMM kernels are
-    two exact-fp32 evaluations of the same step: at the full size, padded frames included, they must agree.
+    """The Winograd kernels (F(2x2,3x3) forward, data gradient, weight gradient; F(2x2,2x2) forward and data gradient of the
+    4x4 stride-2 layers) and the direct implicit-GEMM kernels are two exact-fp32 evaluations of the same step: at the full
+    size, padded frames included, they must agree.
       eval mode (BatchNorm frozen: a well-conditioned backward): loss 1e-5, logits 1e-4, the flat gradient to 1e-3 (observed
         1e-5...2e-4) and every tensor to 5e-3 (observed <= 2.6e-3, on the first layer's weights) -- what is left is the
         handful of ReLU pre-activations within 1e-7 of the kink that the two orders of summation put on opposite sides;
@@ -177,10 +178,11 @@ def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
     C2S, L, E, Fn, LU, synthetic_batch = _mods()
     x, dates, y, lengths = synthetic_batch(B, T, H, H, 1, "cuda", irregular=lengths is None, lengths=lengths)
     results = {}
-    old = E.WINOGRAD
+    old = (E.WINOGRAD, E.S2WINO)
     try:
         for wino in (True, False):
-            E.WINOGRAD = wino
+            E.WINOGRAD = wino            # F(2x2,3x3): the 8-wave / 4-wave kernels and the Winograd weight gradient
+            E.S2WINO = wino              # F(2x2,2x2): the 4x4 stride-2 forward and data gradient
             net = _model(model, "tame").train(mode == "train")
             net.spec.attn_dropout = 0.0
             net.spec.mlp_dropout = 0.0
@@ -190,7 +192,7 @@ def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
             results[wino] = (float(loss), logits.clone(), step.flat_grad.clone(), {n: g.clone() for n, g in step.grads.items()})
             del step, net
     finally:
-        E.WINOGRAD = old
+        E.WINOGRAD, E.S2WINO = old
     (l1, lg1, f1, g1), (l0, lg0, f0, g0) = results[True], results[False]
     flat_rel = float((f1 - f0).double().norm() / f0.double().norm())
     gmax = max(float(g.norm()) for g in g0.values())
