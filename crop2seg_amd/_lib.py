@@ -114,6 +114,8 @@ SIGNATURES = {
     "c2s_ltae_fold_bwd": (I, [P] * 16 + [I, I, I, P, SZ, P]),
     "c2s_ltae_fold_bwd_workspace_floats": (SZ, []),
     "c2s_ltae_pe_table": (I, [I, P, P, F, P, P, P, P, P, I, P]),
+    "c2s_ltae_pe_abs_add": (I, [P, P, P, P, P, I, P]),
+    "c2s_ltae_pe_abs_bwd": (I, [P, P, P, P, I, P]),
     "c2s_ltae_pe_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "c2s_ltae_pe_gattn": (I, [P, P, P, P, I, I, I, P]),
     "c2s_ltae_pe_bwd": (I, [I] + [P] * 15 + [I, I, I, P]),

@@ -246,21 +246,22 @@ class AbsolutePositionalEncoder(_Holder):
 
 def _pe_mode(use_abs_rel_enc, use_doy, add_linear) -> str:
     """Which positional term LTAE.forward adds for a flag combination (tae.py:404-430,467-479)."""
-    if use_abs_rel_enc:
-        if use_doy or add_linear:
-            raise NotImplementedError("use_abs_rel_enc together with use_doy / add_linear is not built")
-        return "abs_rel"
+    if use_abs_rel_enc:                 # + AbsolutePositionalEncoder on batch_positions[...,1] (tae.py:419-422,473)
+        if add_linear:
+            return "abs_rel_linear"     # first encoder: PositionalEncoder(add_linear=True), with or without use_doy
+        return "abs_rel_doy" if use_doy else "abs_rel"
     if add_linear:
         return "linear"                 # with or without use_doy: PositionalEncoder(add_linear=True) (tae.py:405-409,414-417)
     return "doy" if use_doy else "rel"
 
 
 def _positional_encoders(mod, d_model, n_head, T, mode):
-    if mode == "doy":
+    if mode in ("doy", "abs_rel_doy"):
         mod.positional_encoder = AbsolutePositionalEncoder(d_model // n_head, repeat=n_head)
     else:
-        mod.positional_encoder = PositionalEncoder(d_model // n_head, T=T, repeat=n_head, add_linear=mode == "linear")
-    if mode == "abs_rel":
+        mod.positional_encoder = PositionalEncoder(d_model // n_head, T=T, repeat=n_head,
+                                                   add_linear=mode in ("linear", "abs_rel_linear"))
+    if mode.startswith("abs_rel"):
         mod.positional_encoder_abs = AbsolutePositionalEncoder(d_model // n_head, repeat=n_head)
 
 
@@ -372,6 +373,13 @@ class _Backbone(nn.Module):
             object.__setattr__(self, "_ws", ws)
         return ws
 
+    def check_health(self) -> None:
+        """Host-synchronising check of the module's own workspace (the autograd / no-grad forward paths): raises if a
+        one-pass normalisation wait gave up (engine.Workspace.check_sync)."""
+        ws = getattr(self, "_ws", None)
+        if ws is not None:
+            ws.check_sync()
+
     def _check_inputs(self, input: Tensor, batch_positions: Optional[Tensor]):
         if batch_positions is None:
             raise ValueError("batch_positions (acquisition dates [B,T]) is required by the L-TAE positional encoding")
@@ -382,7 +390,10 @@ class _Backbone(nn.Module):
         H, W = input.shape[-2:]
         if H % 8 or W % 8 or H < 16 or W < 16:
             raise ValueError("H and W must be multiples of 8 and >= 16")
-        want = 3 if self.spec.pe_mode == "abs_rel" else 2
+        if input.shape[1] > 64:
+            raise NotImplementedError("crop2seg_amd: the L-TAE kernels hold a whole series per workgroup: at most 64 time steps "
+                                      f"(the dataset's longest series has 61, README.md:92); got T={input.shape[1]}")
+        want = 3 if self.spec.pe_mode.startswith("abs_rel") else 2
         if batch_positions.dim() != want or (want == 3 and batch_positions.shape[-1] != 2):
             raise ValueError("batch_positions must be [B,T,2] (relative date, day of year) with use_abs_rel_enc, else [B,T]")
         if self.spec.num_queries != 1:
@@ -442,6 +453,21 @@ def _common_init(self, model, input_dim, encoder_widths, decoder_widths, out_con
             "mean}, conv_type in {2d, depthwise_separable}, encoder_norm in {group, batch, instance}, add_boundary_loss, encoder, "
             "return_maps, add_squeeze_excit, use_mbconv and the positional encoders of use_doy / use_abs_rel_enc / add_linear; not built: "
             f"{bad or dict(conv_type=conv_type, agg_mode=agg_mode)}")
+    # Limits compiled into the kernels (include/c2s_hip.h, INTEGRATION.md "Shape limits"): raise HERE, naming the limit, not as a
+    # C-ABI error code from the first forward.  The reference builds any combination (train.py:35-43, tae.py:355-449).
+    if (n_head, d_model, d_k) != (16, 256, 4):
+        raise NotImplementedError(
+            f"crop2seg_amd: the L-TAE kernels are built for n_head=16, d_model=256, d_k=4 (the reference's defaults, train.py:40-43); "
+            f"got n_head={n_head}, d_model={d_model}, d_k={d_k}")
+    if (str_conv_k, str_conv_s, str_conv_p) != (4, 2, 1):
+        raise NotImplementedError(
+            f"crop2seg_amd: the strided / transposed convolutions are built for str_conv_k=4, str_conv_s=2, str_conv_p=1 (the "
+            f"reference's defaults, train.py:35-37); got k={str_conv_k}, s={str_conv_s}, p={str_conv_p}")
+    c_ltae = encoder_widths[0] if model == "timeunet" else encoder_widths[-1]
+    if c_ltae % 64 != 0 or c_ltae > 256:
+        raise NotImplementedError(
+            "crop2seg_amd: the L-TAE kernels take a multiple of 64 input channels, at most 256 (encoder_widths[-1]; "
+            f"encoder_widths[0] for TimeUNet_v1); got encoder_widths={list(encoder_widths)}")
     if encoder:
         return_maps = True                      # utae.py:129-130
     if decoder_widths is None:

@@ -485,14 +485,16 @@ extern "C" int c2s_pack_weights_winograd16(const float* src, float* upk, int cin
 
 extern "C" int c2s_conv3x3_winograd16_supported(const c2s_conv_desc* d) {
     return d && d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Hin % 2 == 0 && d->Win % 2 == 0 &&
-           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 3 * W16_CK && (d->C1 == 0 || d->C0 % W16_CK == 0) &&
-           d->N <= 65536;
+           d->Win >= 32 && d->Hin >= 8 && d->CoutP % 64 == 0 && d->C0 + d->C1 > 3 * W16_CK && d->C0 % W16_CK == 0 &&
+           d->C1 % W16_CK == 0 && d->N <= 65536;   // whole chunks only: the chunk's channel base travels in the SGPR offset of the
+                                                   // LDS-DMA loads, which takes no part in the buffer range check -- a ragged
+                                                   // last chunk would read the next frame (ragged counts: the 4-wave kernel)
 }
 
 extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0, const float* src1, const float* upk,
                                       const float* bias, float* out, const int* valid, void* stream) {
     C2S_REQUIRE(d && src0 && upk && out, "conv3x3_winograd16: null pointer");
-    C2S_REQUIRE(c2s_conv3x3_winograd16_supported(d), "conv3x3_winograd16: 3x3 stride 1 pad 1, even planes at least 32 wide and 8 high, CoutP %% 64");
+    C2S_REQUIRE(c2s_conv3x3_winograd16_supported(d), "conv3x3_winograd16: 3x3 stride 1 pad 1, even planes at least 32 wide and 8 high, CoutP %% 64, channels of each source a multiple of 8");
     C2S_REQUIRE(d->N > 0 && d->N <= 65536 && d->C0 > 0 && d->C1 >= 0 && (d->C1 == 0 || src1), "conv3x3_winograd16: bad channels / more than 65536 frames");
     C2S_REQUIRE(d->Hout == d->Hin && d->Wout == d->Win && d->OutH == d->Hout && d->OutW == d->Wout && d->osy == 1 &&
                 d->osx == 1 && d->ooy == 0 && d->oox == 0, "conv3x3_winograd16: dense same-size output only");

@@ -52,6 +52,18 @@ __global__ __launch_bounds__(256) void pe_table_kernel(int mode, const long long
     pe[(size_t)bt * DM + o] = v;
 }
 
+// second encoder of use_abs_rel_enc next to a learnable first one (tae.py:419-422,473): pe[bt,16h+j] += W2[j,day] + b2[j]
+__global__ __launch_bounds__(256) void pe_abs_add_kernel(const long long* __restrict__ d1, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ pe, int* __restrict__ bad) {
+    const int bt = blockIdx.x, o = threadIdx.x, j = o & (DV - 1);
+    long long day = d1[bt];
+    if (day < 0 || day >= NDAY) {
+        if (o == 0) atomicAdd(bad, 1);
+        day = day < 0 ? 0 : NDAY - 1;
+    }
+    pe[(size_t)bt * DM + o] += W[(size_t)j * NDAY + day] + b[j];
+}
+
 __global__ __launch_bounds__(256) void pe_s0_add_kernel(const float* __restrict__ qwk, const float* __restrict__ pe,
                                                         float* __restrict__ s0, int BT) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -187,6 +199,21 @@ extern "C" int c2s_ltae_pe_table(int mode, const long long* dates0, const long l
     hipLaunchKernelGGL(pe_table_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, mode, dates0, dates1, period, W, b, pe,
                        sin256, bad_days);
     C2S_CHECK_LAUNCH("ltae_pe_table");
+    return C2S_OK;
+}
+
+extern "C" int c2s_ltae_pe_abs_add(const long long* dates1, const float* W2, const float* b2, float* pe, int* bad_days, int BT,
+                                   void* stream) {
+    C2S_REQUIRE(dates1 && W2 && b2 && pe && bad_days && BT > 0, "ltae_pe_abs_add: bad args");
+    hipLaunchKernelGGL(pe_abs_add_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, dates1, W2, b2, pe, bad_days);
+    C2S_CHECK_LAUNCH("ltae_pe_abs_add");
+    return C2S_OK;
+}
+
+extern "C" int c2s_ltae_pe_abs_bwd(const long long* dates1, const float* g_pe, float* gW2, float* gb2, int BT, void* stream) {
+    C2S_REQUIRE(dates1 && g_pe && gW2 && gb2 && BT > 0, "ltae_pe_abs_bwd: bad args");
+    hipLaunchKernelGGL(pe_abs_bwd_kernel, dim3(DV), dim3(384), 0, (hipStream_t)stream, dates1, g_pe, gW2, gb2, BT);
+    C2S_CHECK_LAUNCH("ltae_pe_abs_bwd");
     return C2S_OK;
 }
 

@@ -425,7 +425,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 // by all layers of a stream -- never match and nothing is ever cleared: the area only has to be all zero before its first
 // use.  The grid is persistent (at most the workgroups the chip holds at once, positions dealt round-robin), so every
 // workgroup a sweep waits for is resident; a sweep gives up after 2^17 rounds (~0.2 s), raises the error word (header
-// word 3) instead of hanging the queue, and launches on an area whose error word is set do not wait at all.
+// word 3) instead of hanging the queue and makes the group's outputs NaN; launches on an area whose error word is set do not
+// wait at all (incomplete groups come out NaN).  The host side (Workspace.check_sync, called by TrainStep wherever it
+// synchronises anyway) raises on the error word, re-zeroes the area and switches the process to the two-pass kernels.
 struct SyncView {
     unsigned* hdr;                 // [0] finished workgroups, [2] epoch, [3] error
     unsigned long long* gran;      // [nitems][2] {float bits | epoch << 32}
@@ -483,7 +485,10 @@ __device__ __forceinline__ void onepass_sweep(const SyncView& sv, long g0, int w
         }
         if (__all(hit)) break;
         if (polls > (1 << 17)) {
+            // gave up (or the area is poisoned and this group is incomplete): raise the error word and hand NaN partials to the
+            // merge, so that the group's outputs -- and with them the loss -- are NaN instead of plausible numbers from stale sums
             if (lane == 0) __hip_atomic_store(&sv.hdr[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = lane; w < wpg; w += 64) { pa[w] = __uint_as_float(0x7fc00000u); pb[w] = __uint_as_float(0x7fc00000u); }
             break;
         }
         __builtin_amdgcn_s_sleep(4);

@@ -118,17 +118,36 @@ class Workspace:
 
     def sync_area(self, nbytes: int) -> Tensor:
         """Zero-initialised area for kernels whose workgroups meet through memory (one-pass normalisation): all zero at rest
-        (the kernels restore that state themselves), one area per workspace = per stream of launches."""
+        (the kernels restore that state themselves), one area per workspace = per stream of launches.  When the area grows,
+        the error word of the old one is carried over (device copy, stream-ordered)."""
         b = self.bufs.get("sync")
         if b is None or b.numel() < nbytes:
-            b = torch.zeros(max(int(nbytes), 4096), device=self.device, dtype=torch.uint8)
-            self.bufs["sync"] = b
+            nb = torch.zeros(max(int(nbytes), 4096), device=self.device, dtype=torch.uint8)
+            if b is not None:
+                nb[12:16].copy_(b[12:16])
+            b = self.bufs["sync"] = nb
         return b
 
     def sync_error(self) -> int:
-        """Error word of the sync area (host synchronisation: diagnostics / tests only): non-zero when a wait gave up."""
+        """Error word of the sync area (host synchronisation): non-zero when a wait gave up."""
         b = self.bufs.get("sync")
         return 0 if b is None else int(b[:16].view(torch.int32)[3])
+
+    def check_sync(self) -> None:
+        """Raise if a one-pass normalisation wait gave up since the last check (host synchronisation -- call where the
+        caller synchronises anyway).  The groups that gave up wrote NaN, so the step that hit it is lost; recovery: the area
+        is re-zeroed and the process falls back to the two-pass normalisation kernels (`engine.ONEPASS_NORM = False`),
+        which need no residency assumption, so the caller may catch the error and carry on with the next batch."""
+        if self.sync_error() == 0:
+            return
+        global ONEPASS_NORM
+        ONEPASS_NORM = False
+        torch.cuda.synchronize(self.device)
+        self.bufs["sync"].zero_()
+        raise RuntimeError(
+            "crop2seg_amd: a one-pass normalisation wait gave up (the workgroups of a group were not co-resident: "
+            "shared or masked GPU, profiler serialisation?).  The affected outputs are NaN.  The sync area has been "
+            "reset and this process now uses the two-pass normalisation kernels; repeat the step.")
 
     def get(self, name: str, nfloats: int) -> Tensor:
         b = self.bufs.get(name)
@@ -374,9 +393,10 @@ WINO16 = _os.environ.get("C2S_WINO16", "1") != "0"
 S2WINO = _os.environ.get("C2S_S2WINO", "1") != "0"
 
 
-def _wide_winograd(H: int, W: int, cin: int) -> bool:
-    """c2s_conv3x3_winograd16_supported on top of _use_winograd: planes >= 32 wide, at least four chunks of 8 channels."""
-    return WINO16 and W >= 32 and H >= 8 and cin > 24
+def _wide_winograd(H: int, W: int, chans: Sequence[int]) -> bool:
+    """c2s_conv3x3_winograd16_supported on top of _use_winograd: planes >= 32 wide, at least four chunks of 8 channels,
+    whole chunks in every source (ragged channel counts stay on the 4-wave kernel, whose channel index is range-checked)."""
+    return WINO16 and W >= 32 and H >= 8 and sum(chans) > 24 and all(c % 8 == 0 for c in chans)
 
 # bench.py sets PROFILE = {"match": {field: value}, "events": []}: launches whose descriptor matches are bracketed
 # with HIP events on the launch stream (the stream the kernel runs on) for the live roofline measurement.
@@ -486,7 +506,7 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     KK = K * K
     out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
     if _use_winograd(K, S, pad, [C0, C1] if C1 else [C0], Cout, Hin, Win):
-        wide = _wide_winograd(Hin, Win, Cin) and N <= 65536
+        wide = _wide_winograd(Hin, Win, [C0, C1] if C1 else [C0]) and N <= 65536
         upk, CoutP = _pack_winograd(ctx, (wname, "fwd", "wino"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)), wide)
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
         _winograd(d, s0, s1, upk, ctx.p[bname] if bname else None, out, valid, wide)
@@ -544,7 +564,7 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             if S == 1:
                 taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
                 if _use_winograd(K, S, pad, [Cout], Cs, Hin, Win):
-                    wide = _wide_winograd(Hin, Win, Cout) and N <= 65536
+                    wide = _wide_winograd(Hin, Win, [Cout]) and N <= 65536
                     upk, CP = _pack_winograd(ctx, (wname, "dgrad", "wino", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps, wide)
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
                                   accf, radj)
@@ -893,7 +913,9 @@ def positional_table(dates: Tensor, d: int, period: float) -> Tensor:
     return pe
 
 
-PE_MODES = {"rel": 0, "doy": 1, "abs_rel": 2, "linear": 3}
+# "abs_rel_doy" / "abs_rel_linear": use_abs_rel_enc together with use_doy / add_linear (tae.py:407-423): the first encoder
+# (kernel mode 1 / 3 on dates[...,0]) plus the AbsolutePositionalEncoder `positional_encoder_abs` on dates[...,1]
+PE_MODES = {"rel": 0, "doy": 1, "abs_rel": 2, "linear": 3, "abs_rel_doy": 4, "abs_rel_linear": 5}
 
 
 def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor], prefix: str, n_head: int, d_k: int,
@@ -921,17 +943,23 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
         pe = ctx.ws.get("ltae_pe_zero", B * T * 16)
         check(lib().c2s_fill(pe.data_ptr(), B * T * 16, 0.0, _stream()), "fill")
         dl = dates.to(torch.int64)
-        d0 = (dl[..., 0] if mode == 2 else dl).contiguous()
-        d1 = dl[..., 1].contiguous() if mode == 2 else None
+        two = mode in (2, 4, 5)                      # dates [B,T,2]: (relative date, day of year)
+        kmode = {4: 1, 5: 3}.get(mode, mode)         # the table kernel's mode for the first encoder
+        d0 = (dl[..., 0] if two else dl).contiguous()
+        d1 = dl[..., 1].contiguous() if two else None
         enc = prefix + (".positional_encoder_abs.fc" if mode == 2 else ".positional_encoder.fc")
+        enc2 = prefix + ".positional_encoder_abs.fc" if mode in (4, 5) else None
         peW, peb = ctx.p[enc + ".weight"], ctx.p[enc + ".bias"]
         pe256 = torch.empty(B, T, d_model, device=dev, dtype=torch.float32)
-        sin256 = torch.empty(B, T, d_model, device=dev, dtype=torch.float32) if mode == 3 else None
+        sin256 = torch.empty(B, T, d_model, device=dev, dtype=torch.float32) if kmode == 3 else None
         bad = ctx.ws.bufs.get("ltae_pe_bad")
         if bad is None:
             bad = ctx.ws.bufs["ltae_pe_bad"] = torch.zeros(1, device=dev, dtype=torch.int32)
-        check(lib().c2s_ltae_pe_table(mode, d0.data_ptr(), _ptr(d1), float(period), peW.data_ptr(), peb.data_ptr(),
+        check(lib().c2s_ltae_pe_table(kmode, d0.data_ptr(), _ptr(d1), float(period), peW.data_ptr(), peb.data_ptr(),
                                       pe256.data_ptr(), _ptr(sin256), bad.data_ptr(), B * T, _stream()), "ltae_pe_table")
+        if enc2 is not None:
+            check(lib().c2s_ltae_pe_abs_add(d1.data_ptr(), ctx.p[enc2 + ".weight"].data_ptr(), ctx.p[enc2 + ".bias"].data_ptr(),
+                                            pe256.data_ptr(), bad.data_ptr(), B * T, _stream()), "ltae_pe_abs_add")
     # parameter-only fold: U [16,C], s0 [B,T,16]; qwk is kept for the adjoint
     U = torch.empty(n_head, Cc, device=dev, dtype=torch.float32)
     s0 = torch.empty(B, T, n_head, device=dev, dtype=torch.float32)
@@ -1015,10 +1043,15 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
             g_pe = torch.empty(B, T, d_model, device=dev, dtype=torch.float32)
             gW, _ = ctx.grad_sink(enc + ".weight")
             gb, _ = ctx.grad_sink(enc + ".bias")
-            check(lib().c2s_ltae_pe_bwd(mode, d0.data_ptr(), _ptr(d1), Q.data_ptr(), Wk.data_ptr(), qwk.data_ptr(),
+            check(lib().c2s_ltae_pe_bwd(kmode, d0.data_ptr(), _ptr(d1), Q.data_ptr(), Wk.data_ptr(), qwk.data_ptr(),
                                         pe256.data_ptr(), _ptr(sin256), attn.data_ptr(), _ptr(g_emb), gs0.data_ptr(),
                                         g_pe.data_ptr(), sinks[1][0].data_ptr(), sinks[0][0].data_ptr(), gW.data_ptr(),
                                         gb.data_ptr(), B, T, HW, _stream()), "ltae_pe_bwd")
+            if enc2 is not None:
+                gW2, _ = ctx.grad_sink(enc2 + ".weight")
+                gb2, _ = ctx.grad_sink(enc2 + ".bias")
+                check(lib().c2s_ltae_pe_abs_bwd(d1.data_ptr(), g_pe.data_ptr(), gW2.data_ptr(), gb2.data_ptr(), B * T, _stream()),
+                      "ltae_pe_abs_bwd")
         tape.add_grad(x5, gx)
 
     tape.record(bwd)

@@ -51,4 +51,5 @@ def predict_tile(model, x: Tensor, dates: Tensor, grid: int = 10, crop: int = 10
                                            grid, out_h, out_w, E._stream()), "softmax_stitch")
     finally:
         model.train(was_training)
+    model.check_health()                 # one host synchronisation per tile: a failed normalisation wait must not reach a map
     return proba, top1

@@ -160,6 +160,17 @@ class StepMeters:
             if not isinstance(ignore_index, int):
                 raise ValueError("test_region needs an int ignore_index (the reference indexes range(num_classes) with it)")
             self.ignore_label = list(range(num_classes))[ignore_index]
+        self._watched = []
+
+    def watch(self, step) -> "StepMeters":
+        """Register a TrainStep (anything with `check_health()`): the host-synchronising readers below then also surface a
+        failed one-pass normalisation wait of that step's workspace (they raise; see TrainStep.check_health)."""
+        self._watched.append(step)
+        return self
+
+    def _health(self) -> None:
+        for s in self._watched:
+            s.check_health()
 
     def reset(self) -> None:
         self.iou.reset()
@@ -208,11 +219,13 @@ class StepMeters:
         return (pred, pred2) if want_pred else None
 
     def get_miou_acc(self) -> Tuple[float, float]:
+        self._health()
         return self.iou.get_miou_acc()
 
     def get_miou_acc_top2(self) -> Tuple[float, float]:
         return self.iou_top2.get_miou_acc()
 
     def loss_mean(self) -> float:
+        self._health()
         s, n = self.loss_acc.tolist()
         return s / n if n else float("nan")

@@ -151,8 +151,21 @@ class TrainStep:
     def bad_targets(self) -> int:
         """Labels outside [0, num_classes) (other than ignore_index) in the last step's batch: torch's CrossEntropyLoss raises on
         them, the loss kernel skips and counts them -- call this every display_step to surface a mislabelled dataset
-        (host synchronisation)."""
-        return E.bad_target_count(self.ws)
+        (host synchronisation).  Also the place where a failed one-pass normalisation wait surfaces (`check_health`)."""
+        n = E.bad_target_count(self.ws)
+        self.check_health()
+        return n
+
+    def check_health(self) -> None:
+        """Host-synchronising health check (every display_step; `StepMeters.watch(step)` calls it from `get_miou_acc()` /
+        `loss_mean()`): raises if a one-pass normalisation wait gave up (engine.Workspace.check_sync: the area is reset and
+        the process continues on the two-pass kernels).  A captured graph has the one-pass launches baked in, so it is
+        dropped and has to be captured again."""
+        try:
+            self.ws.check_sync()
+        except RuntimeError:
+            self.graph_fb = self.graph_opt = None
+            raise
 
     def _fresh_dropout(self) -> Fn.DropoutState:
         drop = Fn.DropoutState()
@@ -180,7 +193,7 @@ class TrainStep:
         return loss, logits
 
     # ------------------------------------------------------------------------------------------------
-    # hipGraph path: the whole step (about 1,100 kernel launches, ~9 ms of host time when launched eagerly) is
+    # hipGraph path: the whole step (about 335 kernel launches, ~3 ms of host time when launched eagerly) is
     # captured once and replayed.  Everything the step needs to vary between replays lives on the device: the
     # dropout seed offset and the Adam step count are device counters advanced inside the graph.
     @torch.no_grad()
@@ -207,6 +220,7 @@ class TrainStep:
             for k, v in self.model.named_buffers():
                 v.copy_(saved[k])
             torch.cuda.synchronize()
+            self.check_health()                             # never bake a poisoned sync area into a graph
             scale = 1.0 / self.dp.world if self.dp is not None else 1.0
             self.graph_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_fb):
@@ -222,6 +236,8 @@ class TrainStep:
 
     @torch.no_grad()
     def replay(self, x: Optional[Tensor] = None, dates: Optional[Tensor] = None, y: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if getattr(self, "graph_fb", None) is None:
+            raise RuntimeError("TrainStep.replay(): no captured step (capture() was not called, or check_health() dropped it)")
         if x is not None:
             self.static_x.copy_(x)
             self.static_dates.copy_(dates)

@@ -409,9 +409,15 @@ size_t c2s_ltae_fold_bwd_workspace_floats(void);
  *                       emb[b,16h+j,p] += sum_t attn[h,b,t,p] pe256[b,t,16h+j]   (emb may be NULL: W-TAE)
  *   c2s_ltae_pe_gattn : g_attn_out = g_attn_in (or 0) + <g_emb_h, pe256_h>: the upstream gradient c2s_ltae_attn_bwd takes
  *   c2s_ltae_pe_bwd   : after c2s_ltae_attn_bwd and c2s_ltae_fold_bwd: g_pe [BT,256] (scratch output), the pe part of
- *                       d fc1_k.weight / d Q ACCUMULATED into gWk / gQ, and the encoder's parameter gradients gW, gb. */
+ *                       d fc1_k.weight / d Q ACCUMULATED into gWk / gQ, and the encoder's parameter gradients gW, gb.
+ *   c2s_ltae_pe_abs_add / _abs_bwd : use_abs_rel_enc TOGETHER with use_doy / add_linear (tae.py:407-423,473): the first
+ *                       encoder (mode 1 or 3, on dates0) fills pe256, the second -- AbsolutePositionalEncoder on dates1 -- is
+ *                       added to it: pe256[bt,16h+j] += W2[j,dates1] + b2[j]; its parameter gradients from the same g_pe. */
 int c2s_ltae_pe_table(int mode, const long long* dates0, const long long* dates1, float period, const float* W, const float* b,
                       float* pe256, float* sin256, int* bad_days, int BT, void* stream);
+int c2s_ltae_pe_abs_add(const long long* dates1, const float* W2, const float* b2, float* pe256, int* bad_days, int BT,
+                        void* stream);
+int c2s_ltae_pe_abs_bwd(const long long* dates1, const float* g_pe, float* gW2, float* gb2, int BT, void* stream);
 int c2s_ltae_pe_fwd(const float* qwk, const float* pe256, const float* attn, float* s0, float* emb, int B, int T, int HW,
                     int phase, void* stream);
 int c2s_ltae_pe_gattn(const float* g_emb, const float* pe256, const float* g_attn_in, float* g_attn_out, int B, int T, int HW,

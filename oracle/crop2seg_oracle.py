@@ -78,8 +78,8 @@ class BackboneConfig:
     eps: float = 1e-5
 
     def __post_init__(self) -> None:
-        if self.use_abs_rel_enc:
-            self.pe_mode = "abs_rel"
+        if self.use_abs_rel_enc:         # + the second encoder on dates[...,1]; the first follows the other flags (tae.py:407-423)
+            self.pe_mode = "abs_rel_linear" if self.add_linear else ("abs_rel_doy" if self.use_doy else "abs_rel")
         elif self.add_linear:
             self.pe_mode = "linear"      # with or without use_doy (tae.py:405-409,414-417)
         elif self.use_doy:
@@ -332,6 +332,14 @@ def positional_encoding(dates: Tensor, sd: State, prefix: str, cfg: BackboneConf
     if mode == "linear":
         tab = positional_table(dates, dm // H, cfg.pe_period, H, dtype)
         return F.linear(tab, sd[prefix + ".positional_encoder.fc.weight"], sd[prefix + ".positional_encoder.fc.bias"])
+    if mode in ("abs_rel_doy", "abs_rel_linear"):      # tae.py:407-423: both encoders are learnable; :473: their sum
+        w1, b1 = sd[prefix + ".positional_encoder.fc.weight"], sd[prefix + ".positional_encoder.fc.bias"]
+        if mode == "abs_rel_doy":
+            first = absolute_table(dates[..., 0], w1, b1, H)
+        else:
+            first = F.linear(positional_table(dates[..., 0], dm // H, cfg.pe_period, H, dtype), w1, b1)
+        return first + absolute_table(dates[..., 1], sd[prefix + ".positional_encoder_abs.fc.weight"],
+                                      sd[prefix + ".positional_encoder_abs.fc.bias"], H)
     raise ValueError(mode)
 
 

@@ -137,8 +137,22 @@ def test_offdefault_flags_fail_loudly():
     assert len(C2S.WTAE(input_dim=10, out_conv=[32, 20], use_mbconv=True).state_dict()) == 435
     with pytest.raises(NotImplementedError):
         C2S.WTAE(input_dim=10, agg_mode="max")
-    with pytest.raises(NotImplementedError):
-        C2S.UTAE(input_dim=10, use_abs_rel_enc=True, use_doy=True)
+    # compiled-in limits surface in the constructor, naming the limit (not as a C-ABI code from the first forward)
+    with pytest.raises(NotImplementedError, match="n_head=16"):
+        C2S.UTAE(input_dim=10, n_head=8)
+    with pytest.raises(NotImplementedError, match="d_k=4"):
+        C2S.TimeUNet_v1(input_dim=10, d_k=8)
+    with pytest.raises(NotImplementedError, match="str_conv_k=4"):
+        C2S.WTAE(input_dim=10, str_conv_k=3, str_conv_s=1, str_conv_p=1)
+    with pytest.raises(NotImplementedError, match="multiple of 64"):
+        C2S.UTAE(input_dim=10, encoder_widths=[64, 64, 64, 96], decoder_widths=[32, 32, 64, 96])
+    # use_abs_rel_enc together with use_doy / add_linear builds both encoders, as the reference does (tae.py:407-423)
+    sd = C2S.UTAE(input_dim=10, use_abs_rel_enc=True, use_doy=True).state_dict()
+    assert tuple(sd["temporal_encoder.positional_encoder.fc.weight"].shape) == (16, 365)
+    assert tuple(sd["temporal_encoder.positional_encoder_abs.fc.weight"].shape) == (16, 365)
+    sd = C2S.TimeUNet_v1(input_dim=10, use_abs_rel_enc=True, add_linear=True).state_dict()
+    assert tuple(sd["temporal_encoder.positional_encoder.fc.weight"].shape) == (256, 256)
+    assert tuple(sd["temporal_encoder.positional_encoder_abs.fc.weight"].shape) == (16, 365)
 
 
 def test_positional_encoder_flags_extend_the_state_dict_like_the_reference():

@@ -154,6 +154,46 @@ def test_train_step_matches_oracle(goldens):
             assert float((d_ref - d_got).abs().max()) <= 2e-4, n
 
 
+def test_train_step_surfaces_a_failed_normalisation_wait_and_recovers(monkeypatch):
+    """TrainStep reads the sync-area error word wherever it synchronises anyway (bad_targets(), StepMeters readers,
+    capture()): a step on a poisoned area raises there, the area is reset, the process falls back to the two-pass
+    normalisation kernels, and the next step equals the oracle's."""
+    from oracle import crop2seg_oracle as O
+    from oracle import seeded
+    import crop2seg_amd as C2S
+    from crop2seg_amd import engine as E
+    from crop2seg_amd.learning.metrics import StepMeters
+    from crop2seg_amd.learning.utils import TrainStep
+    monkeypatch.setattr(E, "ONEPASS_NORM", True)
+    net = C2S.UTAE(input_dim=10, out_conv=[32, 15])
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = seeded.make_state(ks, 3, "tame")
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    net.spec.attn_dropout = 0.0
+    net.spec.mlp_dropout = 0.0
+    x, dates, y = seeded.make_inputs(2, 4, 10, 32, 32, 91, [4, 3])
+    step = TrainStep(net, num_classes=15)
+    meters = StepMeters(15, ignore_index=-1).watch(step)
+    xd, dd, yd = x.cuda(), dates.cuda(), y.cuda()
+    loss, logits = step(xd, dd, yd, apply_update=False)
+    assert step.bad_targets() == 0                           # healthy: no raise
+    ref_logits, ref_loss, grads, _ = O.loss_and_grads(sd, x, dates, y, O.BackboneConfig(), True)
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    step.ws.bufs["sync"][:16].view(torch.int32)[3] = 1       # a wait gave up
+    loss, logits = step(xd, dd, yd, apply_update=False)
+    meters.update(logits, yd, loss)
+    with pytest.raises(RuntimeError, match="one-pass normalisation wait gave up"):
+        meters.loss_mean()
+    assert E.ONEPASS_NORM is False
+    loss, logits = step(xd, dd, yd, apply_update=False)      # two-pass kernels: same numbers as the oracle again
+    assert step.bad_targets() == 0
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    assert float((logits.cpu() - ref_logits).abs().max()) < 1e-3 * float(ref_logits.abs().max())
+    n = "in_conv.conv.conv.0.weight"
+    assert float((step.grads[n].cpu() - grads[n]).norm() / grads[n].norm()) < 1e-3
+
+
 @pytest.mark.parametrize("name,smoothing", [("utae_train_mean_boundary_tame", 0.0), ("utae_train_p0_tame", 0.1)])
 def test_train_step_boundary_and_smoothing_match_oracle(goldens, name, smoothing):
     """TrainStep with the boundary head (CE + focal loss through the HIP loss kernels, both heads on the tape) and with

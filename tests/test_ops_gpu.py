@@ -101,6 +101,12 @@ WIDE_WINOGRAD_CASES = [
     (1, 32, 0, 72, 12, 40, "reflect"),          # ragged: partial tiles in both directions, padded output channels
     (2, 40, 0, 64, 8, 32, "zeros"),             # one tile per frame, zero padding, 5 chunks
     (2, 32, 64, 64, 32, 64, "reflect"),         # two sources (the decoder's [up, skip])
+    # ragged channel counts (not a multiple of the 8-channel chunk): must stay OFF the 8-wave kernel -- its chunk base travels
+    # in an SGPR offset that the buffer range check ignores -- and be right on the 4-wave kernel; N = 1: an over-read of the
+    # last chunk would leave the allocation
+    (1, 36, 0, 64, 16, 32, "reflect"),
+    (1, 100, 0, 64, 8, 32, "zeros"),
+    (1, 64, 0, 36, 16, 32, "reflect"),          # ragged Cout: the data gradient's input channels
 ]
 
 
@@ -128,7 +134,13 @@ def test_conv2d_wide_winograd(case):
     old = E.WINO16
     E.WINO16 = True
     try:
-        assert E._use_winograd(3, 1, 1, [C0, C1] if C1 else [C0], Cout, H, W) and E._wide_winograd(H, W, Cin)
+        chans = [C0, C1] if C1 else [C0]
+        ragged = any(c % 8 for c in chans)
+        dsc = L.ConvDesc(N, C0, C1, H, W, Cout, (Cout + 63) // 64 * 64, H, W, H, W, 3, 3, 1, 1, 1, L.PAD_ZEROS, 1, 1, 0, 0, 0)
+        assert bool(L.lib().c2s_conv3x3_winograd16_supported(ctypes.byref(dsc))) == (not ragged)
+        if Cout >= 64:
+            assert E._use_winograd(3, 1, 1, chans, Cout, H, W) and E._wide_winograd(H, W, chans) == (not ragged)
+        assert not E._wide_winograd(H, W, [36])
         out = E.conv2d(ctx, srcs, "w", "b", 3, 1, 1, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZEROS, valid.cuda())
         assert rel(out[keep.cuda()], ref) < 2e-6
         gfull = torch.zeros(N, *ref.shape[1:])
@@ -349,6 +361,49 @@ def test_norm_relu_fwd_bwd(kind, shape, use_res, use_valid, onepass, monkeypatch
     if use_res:
         assert rel(ctx.tape.grads[rd.data_ptr()][keep.cuda()], res.grad[keep]) < 1e-6
     assert ctx.ws.sync_error() == 0, "a one-pass normalisation wait gave up"
+
+
+def test_norm_onepass_failed_wait_is_loud_and_recoverable(monkeypatch):
+    """A sweep that gave up leaves the error word set (hdr[3]).  From then on: incomplete groups come out NaN (never plausible
+    numbers from stale partial sums), `Workspace.check_sync()` raises, re-zeroes the area and switches the process to the
+    two-pass kernels, whose result equals torch's.  The error word is pre-set here (the premise is not reproduced by
+    repetition): every multi-wave group of a poisoned area whose partners have not published yet must be NaN or correct."""
+    E, L = _engine()
+    monkeypatch.setattr(E, "ONEPASS_NORM", True)
+    monkeypatch.setattr(E, "ONEPASS_MIN_HW", 256)
+    g = torch.Generator().manual_seed(3)
+    N, C, H = 8, 64, 128
+    x = torch.randn(N, C, H, H, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    ref = F.relu(F.group_norm(x, 4, gamma, beta, 1e-5))
+    xd = x.cuda()
+    ctx = make_ctx({"n.weight": gamma, "n.bias": beta}, {})
+    out = E.norm_act(ctx, xd, "n", L.NORM_GROUP, 4, True, None, None, 0.0)
+    assert rel(out, ref) < 2e-6 and ctx.ws.sync_error() == 0
+    ctx.ws.check_sync()                                   # healthy: no raise
+    ctx.ws.bufs["sync"][:16].view(torch.int32)[3] = 1     # a wait gave up
+    bad = E.norm_act(ctx, xd, "n", L.NORM_GROUP, 4, True, None, None, 0.0)
+    torch.cuda.synchronize()
+    # every (frame, group) block is either complete (all partners had published when its sweep looked) or entirely NaN
+    blocks = bad.view(N, 4, -1)
+    nan_blocks = torch.isnan(blocks).all(dim=2)
+    ok_blocks = ~torch.isnan(blocks).any(dim=2)
+    assert bool((nan_blocks | ok_blocks).all())
+    good = ok_blocks.cpu()
+    if bool(good.any()):
+        assert rel(blocks.cpu()[good], ref.view(N, 4, -1)[good]) < 2e-6
+    with pytest.raises(RuntimeError, match="one-pass normalisation wait gave up"):
+        ctx.ws.check_sync()
+    assert E.ONEPASS_NORM is False and ctx.ws.sync_error() == 0
+    ctx.ws.check_sync()                                   # recovered: no raise
+    out2 = E.norm_act(ctx, xd, "n", L.NORM_GROUP, 4, True, None, None, 0.0)       # two-pass kernels now
+    assert rel(out2, ref) < 2e-6
+    # the error word survives a growing area
+    monkeypatch.setattr(E, "ONEPASS_NORM", True)
+    ws = E.Workspace(xd.device)
+    ws.sync_area(4096)[:16].view(torch.int32)[3] = 1
+    ws.sync_area(1 << 20)
+    assert ws.sync_error() == 1
 
 
 def test_norm_onepass_under_uneven_load_matches_two_pass(monkeypatch):
