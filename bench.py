@@ -10,8 +10,9 @@ T = 32 x 10 x 128 x 128) in fp32 -- the arithmetic type of the reference; the bf
 counterpart and is not claimed.  N > 1: one process per GPU (torch.distributed.run), B = 4 per GPU
 (weak scaling), one flat 4.3 MB gradient all-reduce per step.
 
-Prints ONE JSON line on rank 0 with the roofline of the dominant kernel (the 64->64 3x3 implicit-GEMM convolution at
-128x128, timed with HIP events on the launch stream inside the timed region) and the CPU baseline (the CPU oracle --
+Prints ONE JSON line on rank 0 with the roofline of the dominant kernel (the 64->64 3x3 convolution of the in_conv block at
+128x128 -- the 8-wave Winograd F(2x2,3x3) kernel conv_winograd16_kernel<false> --, timed with HIP events on the launch
+stream inside the timed region) and the CPU baseline (the CPU oracle --
 a restatement of the reference validated against it -- timed on this host's cores on a bounded sample).
 """
 from __future__ import annotations
@@ -227,7 +228,7 @@ def main():
         # where the direct form needs 36 -- the roofline fraction is priced on the EXECUTED count (<= 1 by construction)
         flops_exec = flops_algo * (16.0 / 36.0 if wino else 1.0)
         achieved = flops_exec / (kernel_ms * 1e-3) / 1e12 if ms else 0.0
-        kname = ("conv_winograd16_kernel<false>" if E._wide_winograd(H, H, 64) else "conv_winograd_kernel<4,false>") if wino \
+        kname = ("conv_winograd16_kernel<false>" if E._wide_winograd(H, H, [64]) else "conv_winograd_kernel<4,false>") if wino \
             else "conv_igemm_kernel<3,1,2,false>"
         traffic, traffic_src = dominant_traffic(kname, N, H)
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

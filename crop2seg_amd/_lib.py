@@ -123,6 +123,7 @@ SIGNATURES = {
     "c2s_ltae_attn_fwd_ws": (I, [C.POINTER(LtaeDesc)] + [P] * 13 + [P, SZ, P]),
     "c2s_ltae_uses_streaming": (I, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_fwd_path": (I, [C.POINTER(LtaeDesc)]),
+    "c2s_ltae_attn_optional": (I, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_bwd_workspace_floats": (SZ, [C.POINTER(LtaeDesc)]),
     "c2s_ltae_attn_bwd": (I, [C.POINTER(LtaeDesc)] + [P] * 22 + [SZ, P]),
     "c2s_dropout_nchw": (I, [P, P, I, I, I, F, C.c_uint64, P, P, P]),

@@ -175,11 +175,12 @@ def up_conv_block(ctx, x, skip, prefix, spec):
     return conv_layer(ctx, [o1], prefix + ".conv2", 1, "batch", 3, 1, 1, spec, None, residual=o1)
 
 
-def ltae(ctx, x5, dates, valid, prefix, spec: BackboneSpec, drop: DropoutState, with_tail: bool):
-    """LTAE.forward / LTAE4WTAE.forward (reference tae.py:451-504, 589-635)."""
+def ltae(ctx, x5, dates, valid, prefix, spec: BackboneSpec, drop: DropoutState, with_tail: bool, need_attn: bool = True):
+    """LTAE.forward / LTAE4WTAE.forward (reference tae.py:451-504, 589-635).  need_attn=False: the attention masks have no
+    reader (TimeUNet_v1 hands them to the caller only with return_att, timeunet.py:204-205); they may come back as None."""
     emb, attn = E.ltae_attention(ctx, x5, dates, valid, prefix, spec.n_head, spec.d_k, spec.d_model, spec.pe_period,
                                  spec.attn_dropout, with_tail, drop.attn_seed, drop.attn_keep, drop.seed_dev,
-                                 pe_mode=spec.pe_mode)
+                                 pe_mode=spec.pe_mode, need_attn=need_attn)
     if not with_tail:
         return None, attn
     o = E.conv2d(ctx, [emb], prefix + ".mlp.0.weight", prefix + ".mlp.0.bias", 1, 1, 0, _lib.PAD_ZEROS, None)
@@ -255,7 +256,7 @@ def timeunet_forward(ctx, spec, x5, dates, drop):
     se = spec.add_squeeze_excit
     f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws,
                     add_squeeze=se)
-    out, att = ltae(ctx, _unfold(f0, B, T), dates, valid, "temporal_encoder", spec, drop, True)
+    out, att = ltae(ctx, _unfold(f0, B, T), dates, valid, "temporal_encoder", spec, drop, True, need_attn=ctx.want_att)
     fmaps = [out]
     n_stages = len(spec.encoder_widths)
     for i in range(n_stages - 1):

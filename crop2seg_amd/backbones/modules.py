@@ -426,6 +426,7 @@ class _Backbone(nn.Module):
         else:
             with torch.no_grad():
                 ectx = E.Ctx(dict(named), dict(self.named_buffers()), None, self._workspace(x.device), self.training, None)
+                ectx.want_att = bool(return_att)
                 out = Fn.FORWARDS[spec.model](ectx, spec, x, dates, drop)
                 att, diff = out.att, _pack_outputs(out)
         # tuple conventions of the reference (utae.py:233-252, wtae.py:259-279, timeunet.py:201-210)

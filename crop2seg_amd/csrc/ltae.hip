@@ -1478,7 +1478,8 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
                     const float ks = rng ? drop_pick(dc, bits[i >> 1], t) : keep_scale(p, h, Ptot, pidx, t);
                     ad = a * ks;
                     if (p.attn_pre != nullptr) (p.attn_pre + (size_t)(b * T + t) * HW)[hoff[r]] = a;
-                    (p.attn + (size_t)(b * T + t) * HW)[hoff[r]] = ad;
+                    if (p.attn != nullptr) (p.attn + (size_t)(b * T + t) * HW)[hoff[r]] = ad;    // NULL: nobody reads the post-dropout
+                                                                                                 // weights (TimeUNet without return_att)
                     as += ad;
                 }
                 sc[i][r] = ad;
@@ -2108,6 +2109,10 @@ __device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, unsign
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
+// REKEEP: the forward did not store the post-dropout weights (attn_in == NULL): the keep flags are re-derived from the
+// counter hash of the forward (same seed, same (row, pair of steps) counters) -- one tensor less to read.  Only for the RNG
+// mask (an explicit keep tensor comes with the stored weights); p = 0 gives threshold 0 and scale 1.
+template <bool REKEEP>
 __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, StreamBwd sb) {
     extern __shared__ float lds[];
     float* aL = lds + RB_A;
@@ -2136,8 +2141,8 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
     const unsigned abytes = 16u * (unsigned)(p.B * T) * rowb;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * T * C * HW), 0, (int)((unsigned)(T * C) * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t rap = __builtin_amdgcn_make_buffer_rsrc((void*)p.attn_pre_in, 0, (int)abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)p.attn_in, 0, (int)abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rga = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g_attn != nullptr ? p.g_attn : p.attn_in), 0, (int)abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)(REKEEP ? p.attn_pre_in : p.attn_in), 0, (int)abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rga = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g_attn != nullptr ? p.g_attn : p.attn_pre_in), 0, (int)abytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((void*)p.GS, 0, (int)abytes, 0x00020000);
     const float gat_w = p.g_attn != nullptr ? 1.f : 0.f;   // no upstream gradient of the attention output: weight 0
     const unsigned xvo = ((unsigned)(16 * q) * (unsigned)HW + (unsigned)pix) * 4u;
@@ -2156,6 +2161,9 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
     const bool dropping = p.drop_p > 0.f;
     const float thr16 = (float)(uint32_t)(p.drop_p * 65536.f + 0.5f);
     const float kscale = !dropping ? 1.f : (p.keep != nullptr ? 1.f / (1.f - p.drop_p) : 65536.f / (65536.f - thr16));
+    DropCtx dc = {};
+    if constexpr (REKEEP) dc = drop_ctx(p);        // (uniform scalar work; thr = 0, inv = 1 without dropout)
+    const long Ptot = (long)p.B * HW;
 
     LT_STAMP_B(0);
     // ---- P0 .. H1, ordered for the load queue (a wave has 64 loads in flight at most and issues in order): the small operands
@@ -2364,8 +2372,22 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     apk[4 * ih + ii][r] = bload(rap, hv0, trow(4 * ih + ii, r));
-                    adv[ii][r] = bload(rad, hv0, trow(4 * ih + ii, r));
+                    if constexpr (!REKEEP) adv[ii][r] = bload(rad, hv0, trow(4 * ih + ii, r));
                 }
+            if constexpr (REKEEP) {
+                // attn = attn_pre * keep-scale with the forward's hash: t0 is even, steps (2u, 2u+1) of a row share one hash
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t rb = (uint64_t)((long)(4 * q + r) * Ptot + pidx) * (uint64_t)dc.half_t + (uint64_t)((t0 >> 1) + 2 * ih);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint64_t i2 = rb + (uint64_t)u;
+                        const uint32_t bits = c2s_hash32((uint32_t)i2 ^ dc.key ^ (uint32_t)(i2 >> 32) * 0x85EBCA6Bu);
+                        adv[2 * u][r] = apk[4 * ih + 2 * u][r] * ((bits & 0xffffu) >= dc.thr ? dc.inv : 0.f);
+                        adv[2 * u + 1][r] = apk[4 * ih + 2 * u + 1][r] * ((bits >> 16) >= dc.thr ? dc.inv : 0.f);
+                    }
+                }
+            }
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = 4 * ih + ii;
@@ -2607,7 +2629,8 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
     const int tiles_per_b = HW / 64;
     const int b = (int)(tile / tiles_per_b);
     const int pix = (int)(tile % tiles_per_b) * 64 + lane;
-    const long pidx = (long)b * HW + pix;
+    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
+    const bool rekeep = p.attn_in == nullptr;      // the forward stored the pre-dropout weights only: keep flags from its hash
     const int g = w;
 
     // ---- r[h][c][px] = sum_j Wc[16h+j][c] ge[16h+j][px] on the MFMA, wave = head:  4 channel tiles x 4 pixel tiles x 4 k-steps
@@ -2684,7 +2707,7 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
                 const int arr = row >> 8, tt = (row >> 4) & 15, h = row & 15;
                 const int t = tc0 + tt < T ? tc0 + tt : T - 1;
                 const size_t o = (size_t)h * hstride + ((size_t)b * T + t) * HW + pix;
-                v[i] = arr == 0 ? p.attn_in[o] : p.GS[o];
+                v[i] = arr == 0 ? (rekeep ? p.attn_pre_in[o] * keep_scale(p, h, Ptot, pidx, t) : p.attn_in[o]) : p.GS[o];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -2792,7 +2815,8 @@ void init_hook() {
     C2S_RAISE_LDS(ltae_stream_bwd_heads_kernel<4>);
     C2S_RAISE_LDS(ltae_stream_bwd_gx_kernel<4>);
     C2S_RAISE_LDS(ltae_stream_bwd_gx64_kernel);
-    C2S_RAISE_LDS(ltae_reg_bwd_heads_kernel);
+    C2S_RAISE_LDS(ltae_reg_bwd_heads_kernel<false>);
+    C2S_RAISE_LDS(ltae_reg_bwd_heads_kernel<true>);
     C2S_RAISE_LDS(ltae_reg_fwd_kernel);
 }
 C2sInitRegistrar registrar(init_hook);
@@ -2836,12 +2860,32 @@ extern "C" int c2s_ltae_fwd_path(const c2s_ltae_desc* d) {
     return use_reg_fwd(d) ? 2 : (use_stream(d) ? 1 : 0);
 }
 
+static bool reg_bwd_enabled() {
+    static const bool on = [] { const char* e = getenv("C2S_LTAE_REG_BWD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// register-resident heads kernel + 64-px dx kernel; its buffer descriptors address < 2^31 bytes per tensor
+static bool use_reg_bwd(const c2s_ltae_desc* d, bool with_emb) {
+    return with_emb && use_stream(d) && reg_bwd_enabled() && use_reg_fwd(d) && d->HW % 64 == 0 &&
+           (size_t)16 * d->B * d->T * d->HW < ((size_t)1 << 29) && (size_t)d->T * d->C * d->HW < ((size_t)1 << 29);
+}
+
+// 1 when a caller that never reads the post-dropout weights may pass attn == NULL to c2s_ltae_attn_fwd_ws AND to
+// c2s_ltae_attn_bwd (both take the register-resident kernels for this shape; RNG mask, embedding output)
+extern "C" int c2s_ltae_attn_optional(const c2s_ltae_desc* d) {
+    return d && check(d) == C2S_OK && d->keep == nullptr && use_reg_bwd(d, true) ? 1 : 0;
+}
+
 extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
                                     const float* U, const float* s0, const float* Wc, const float* bc, const float* pe,
                                     const int* valid, float* attn, float* attn_pre, float* emb, float* stats,
                                     float* workspace, size_t ws_floats, void* stream) {
     if (int rc = check(d)) return rc;
-    C2S_REQUIRE(x && gamma && beta && U && s0 && attn && stats, "ltae_fwd: null pointer");
+    C2S_REQUIRE(x && gamma && beta && U && s0 && stats, "ltae_fwd: null pointer");
+    // attn == NULL: the caller never reads the post-dropout weights (TimeUNet without return_att); only the register-resident
+    // forward skips the store; a later backward then needs attn_pre and the RNG mask (c2s_ltae_attn_optional)
+    C2S_REQUIRE(attn != nullptr || (use_reg_fwd(d) && emb != nullptr),
+                "ltae_fwd: attn may only be NULL on the register-resident path (c2s_ltae_fwd_path == 2) with an embedding output");
     C2S_REQUIRE(emb == nullptr || (Wc && bc && pe), "ltae_fwd: embedding output needs Wc, bc, pe");
     LtaeParams p = {};
     fill(p, d);
@@ -2892,16 +2936,15 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
                                  float* gbc, float* ggamma, float* gbeta, float* workspace, size_t ws_floats,
                                  void* stream) {
     if (int rc = check(d)) return rc;
-    C2S_REQUIRE(x && gamma && beta && U && Wc && bc && pe && attn && attn_pre && stats && gx && gU && gs0 && gWc && gbc &&
+    C2S_REQUIRE(x && gamma && beta && U && Wc && bc && pe && attn_pre && stats && gx && gU && gs0 && gWc && gbc &&
                     ggamma && gbeta && workspace,
                 "ltae_bwd: null pointer");
     C2S_REQUIRE(ws_floats >= c2s_ltae_bwd_workspace_floats(d), "ltae_bwd: workspace too small");
     (void)s0; (void)valid;
     const bool stream_path = g_emb != nullptr && use_stream(d);
-    static const bool reg_bwd_on = [] { const char* e = getenv("C2S_LTAE_REG_BWD"); return !(e && e[0] == '0'); }();
-    // register-resident heads kernel + 64-px dx kernel; its buffer descriptors address < 2^31 bytes per tensor
-    const bool reg_heads = stream_path && reg_bwd_on && use_reg_fwd(d) && d->HW % 64 == 0 &&
-                           (size_t)16 * d->B * d->T * d->HW < ((size_t)1 << 29) && (size_t)d->T * d->C * d->HW < ((size_t)1 << 29);
+    const bool reg_heads = use_reg_bwd(d, g_emb != nullptr);
+    C2S_REQUIRE(attn != nullptr || (reg_heads && d->keep == nullptr),
+                "ltae_bwd: attn may only be NULL where the forward could omit it (register-resident path, RNG mask)");
     const int PT = reg_heads ? RPX : (stream_path ? SPT : bwd_pt(d));
     const size_t tiles = (size_t)d->B * ((d->HW + PT - 1) / PT);
     const size_t tiles_ws = (size_t)d->B * ((d->HW + 7) / 8);
@@ -2925,7 +2968,8 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         const size_t lds1 = ((size_t)NH * d->C * SPT + NH * 2 * SPT + 2 * NH * SPT + 2 * SCH * 4 * SPT * 4 + (size_t)d->T * DV) * sizeof(float);
         if (reg_heads) {
             sb.gb64 = p.part_gb;                   // d gamma / d beta partials come from the dx kernel, one per 64-pixel tile
-            hipLaunchKernelGGL(ltae_reg_bwd_heads_kernel, dim3(tiles), dim3(512), RB_FLOATS * sizeof(float), st, p, sb);
+            if (attn == nullptr) hipLaunchKernelGGL(ltae_reg_bwd_heads_kernel<true>, dim3(tiles), dim3(512), RB_FLOATS * sizeof(float), st, p, sb);
+            else hipLaunchKernelGGL(ltae_reg_bwd_heads_kernel<false>, dim3(tiles), dim3(512), RB_FLOATS * sizeof(float), st, p, sb);
         } else {
             hipLaunchKernelGGL(ltae_stream_bwd_heads_kernel<4>, dim3(tiles), dim3(1024), lds1, st, p, sb);
         }

@@ -641,6 +641,7 @@ __global__ __launch_bounds__(256) void norm_onepass_fwd_kernel(const float* __re
         }
         const float a = gamma[c] * rstd, b = beta[c];
         if (s.seg == 0 && lane == 0) { row_ab[s.row * 3] = a; row_ab[s.row * 3 + 1] = b; row_ab[s.row * 3 + 2] = mu; }
+        const bool failed = mu != mu;                            // the sweep gave up (NaN partials): fmaxf would turn NaN into 0
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             f32x4 o;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(256) void norm_onepass_fwd_kernel(const float* __re
                 float t = (s.xv[k][e] - mu) * a + b;
                 if (relu) t = fmaxf(t, 0.f);
                 if constexpr (RES) t += rv[k][e];
-                o[e] = t;
+                o[e] = failed ? mu : t;
             }
             *reinterpret_cast<f32x4*>(y + s.base + lane * 4 + 256 * k) = o;
         }

@@ -258,6 +258,8 @@ class Ctx:
         self._packed: Dict[Tuple, Tensor] = {}
         self._plan_ran = False
         self._gwritten: set = set()
+        self.want_att = True      # False: the caller never reads the attention masks a forward returns (TrainStep; inference
+                                  # without return_att): TimeUNet's full-resolution L-TAE then does not store them
         cus = lib().c2s_device_cus()
         self.cus = cus if cus > 0 else 256
 
@@ -920,11 +922,15 @@ PE_MODES = {"rel": 0, "doy": 1, "abs_rel": 2, "linear": 3, "abs_rel_doy": 4, "ab
 
 def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor], prefix: str, n_head: int, d_k: int,
                    d_model: int, period: float, dropout_p: float, with_embedding: bool, seed: int,
-                   keep: Optional[Tensor], seed_dev: Optional[Tensor] = None, pe_mode: str = "rel") -> Tuple[Optional[Tensor], Tensor]:
+                   keep: Optional[Tensor], seed_dev: Optional[Tensor] = None, pe_mode: str = "rel",
+                   need_attn: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """L-TAE steps 1-6 (reference tae.py:451-481, 738-847).  Returns (emb [B,d_model,h,w] | None, attn [H,B,T,h,w]).
     pe_mode: "rel" = the default sinusoid of the relative dates; "doy" / "abs_rel" / "linear" = the learnable encoders of
     use_doy / use_abs_rel_enc (dates [B,T,2]) / add_linear (tae.py:404-430): the attention kernels then run with a zero
-    table and the general table enters next to them (csrc/ltae_pe.hip)."""
+    table and the general table enters next to them (csrc/ltae_pe.hip).
+    need_attn=False: the caller never reads the post-dropout weights (TimeUNet_v1 without return_att): where the kernels allow
+    it (c2s_ltae_attn_optional) they are not stored -- the returned attn is then None -- and the backward re-derives the
+    keep flags from the forward's counter hash."""
     B, T, Cc, h, w = x5.shape
     HW = h * w
     Q = ctx.p[prefix + ".attention_head.Q"]
@@ -972,11 +978,13 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     Wc = Wc3.view(d_model, Cc)
     p_eff = dropout_p if ctx.training else 0.0
     d = LtaeDesc(B, T, Cc, HW, n_head, d_model, ctx.eps, p_eff, seed, _ptr(keep) if p_eff > 0 else None, _ptr(seed_dev))
-    attn = torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
+    skip_attn = not need_attn and mode == 0 and with_embedding and (
+        bool(lib().c2s_ltae_attn_optional(C.byref(d))) if ctx.tape is not None else lib().c2s_ltae_fwd_path(C.byref(d)) == 2)
+    attn = None if skip_attn else torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
     # softmax before dropout: saved for the backward (and the score scratch of the three-pass streaming kernels); a forward
     # without a tape (inference) does not store it: 16*B*T*h*w floats less to write
     need_pre = ctx.tape is not None or lib().c2s_ltae_fwd_path(C.byref(d)) == 1
-    attn_pre = torch.empty_like(attn) if need_pre else None
+    attn_pre = torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32) if need_pre else None
     emb = torch.empty(B, d_model, h, w, device=x5.device, dtype=torch.float32) if with_embedding else None
     stats = torch.empty(B * HW * n_head * 2, device=x5.device, dtype=torch.float32)
     Ud, s0d = U, s0
@@ -988,7 +996,7 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
         e0.record()
     check(lib().c2s_ltae_attn_fwd_ws(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
                                      s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
-                                     attn.data_ptr(), _ptr(attn_pre), _ptr(emb), stats.data_ptr(), fws.data_ptr(),
+                                     _ptr(attn), _ptr(attn_pre), _ptr(emb), stats.data_ptr(), fws.data_ptr(),
                                      fws.numel(), _stream()), "ltae_fwd")
     if timed:
         e1.record()
@@ -999,12 +1007,13 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     if ctx.tape is None:
         return emb, attn
     tape = ctx.tape
-    tape.track(attn)
+    if attn is not None:
+        tape.track(attn)
     if emb is not None:
         tape.track(emb)
 
     def bwd():
-        g_attn = tape.pop_grad(attn)
+        g_attn = tape.pop_grad(attn) if attn is not None else None
         g_emb = tape.pop_grad(emb) if emb is not None else None
         if g_attn is None and g_emb is None:
             return
@@ -1025,7 +1034,7 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
             g_attn = g_tot
         check(lib().c2s_ltae_attn_bwd(C.byref(d), x5.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Ud.data_ptr(),
                                       s0d.data_ptr(), Wc.data_ptr(), bc.data_ptr(), pe.data_ptr(), _ptr(valid),
-                                      attn.data_ptr(), attn_pre.data_ptr(), stats.data_ptr(), _ptr(g_emb), _ptr(g_attn),
+                                      _ptr(attn), attn_pre.data_ptr(), stats.data_ptr(), _ptr(g_emb), _ptr(g_attn),
                                       gx.data_ptr(), gU.data_ptr(), gs0.data_ptr(), gWc.data_ptr(), gbc.data_ptr(),
                                       ggam.data_ptr(), gbet.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ltae_bwd")
         # adjoint of the parameter fold: final gradients of Q, fc1_k, inconv in one launch

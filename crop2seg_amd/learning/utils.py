@@ -129,6 +129,7 @@ class TrainStep:
         model = self.model
         tape = E.Tape()
         ctx = E.Ctx(self.params, dict(model.named_buffers()), self.grads, self.ws, model.training, tape)
+        ctx.want_att = False                             # the step returns (loss, logits): nobody reads the attention masks
         out = Fn.FORWARDS[model.spec.model](ctx, model.spec, x, dates, drop)
         logits = out.logits
         loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True, label_smoothing=self.label_smoothing)

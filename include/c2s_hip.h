@@ -374,6 +374,12 @@ int c2s_ltae_uses_streaming(const c2s_ltae_desc* d);
  * 1 = the three-pass streaming kernels (ltae_prep + ltae_stream_fwd), 2 = the register-resident kernel (ltae_reg_fwd_kernel);
  * -1 = bad descriptor.  (Measurement harnesses label their numbers with it.) */
 int c2s_ltae_fwd_path(const c2s_ltae_desc* d);
+/* 1 when a caller that never reads the post-dropout attention weights (TimeUNet_v1.forward without return_att,
+ * timeunet.py:176-178,204-205) may pass attn == NULL to c2s_ltae_attn_fwd_ws AND to c2s_ltae_attn_bwd: both then take the
+ * register-resident kernels, the forward stores attn_pre only (16*B*T*hw floats less to write) and the backward re-derives
+ * the keep flags from the forward's counter hash (as many floats less to read).  Needs the RNG mask (d->keep == NULL) and
+ * the embedding output. */
+int c2s_ltae_attn_optional(const c2s_ltae_desc* d);
 size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
 /* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],
  * gU [16,C], gs0 [B,T,16], gWc [256,C] (embedding path only), gbc [256], ggamma [C], gbeta [C]. */

@@ -2,6 +2,7 @@
 (oracle/crop2seg_oracle.py restatements + torch CPU autograd on them).  Tolerances: fp32 kernels vs an fp32 (or
 fp64) CPU evaluation of the same formula; the north star's bar is 1e-3 relative, the kernels are held to 1e-4..1e-5
 unless stated."""
+import ctypes
 import math
 
 import pytest
@@ -367,7 +368,7 @@ def test_norm_onepass_failed_wait_is_loud_and_recoverable(monkeypatch):
     """A sweep that gave up leaves the error word set (hdr[3]).  From then on: incomplete groups come out NaN (never plausible
     numbers from stale partial sums), `Workspace.check_sync()` raises, re-zeroes the area and switches the process to the
     two-pass kernels, whose result equals torch's.  The error word is pre-set here (the premise is not reproduced by
-    repetition): every multi-wave group of a poisoned area whose partners have not published yet must be NaN or correct."""
+    repetition): launches on a poisoned area do not wait, so a wave whose partners have not published yet must write NaN."""
     E, L = _engine()
     monkeypatch.setattr(E, "ONEPASS_NORM", True)
     monkeypatch.setattr(E, "ONEPASS_MIN_HW", 256)
@@ -384,14 +385,15 @@ def test_norm_onepass_failed_wait_is_loud_and_recoverable(monkeypatch):
     ctx.ws.bufs["sync"][:16].view(torch.int32)[3] = 1     # a wait gave up
     bad = E.norm_act(ctx, xd, "n", L.NORM_GROUP, 4, True, None, None, 0.0)
     torch.cuda.synchronize()
-    # every (frame, group) block is either complete (all partners had published when its sweep looked) or entirely NaN
-    blocks = bad.view(N, 4, -1)
-    nan_blocks = torch.isnan(blocks).all(dim=2)
-    ok_blocks = ~torch.isnan(blocks).any(dim=2)
-    assert bool((nan_blocks | ok_blocks).all())
-    good = ok_blocks.cpu()
+    # every wave's (row, 2048-float segment) is either right (all partners of its group had published when its workgroup's sweep
+    # looked) or entirely NaN -- never a plausible number from stale partial sums, and not a zero behind the ReLU either
+    segs = bad.view(N * C, -1, 2048)
+    nan_segs = torch.isnan(segs).all(dim=2)
+    ok_segs = ~torch.isnan(segs).any(dim=2)
+    assert bool((nan_segs | ok_segs).all())
+    good = ok_segs.cpu()
     if bool(good.any()):
-        assert rel(blocks.cpu()[good], ref.view(N, 4, -1)[good]) < 2e-6
+        assert rel(segs.cpu()[good], ref.view(N * C, -1, 2048)[good]) < 2e-6
     with pytest.raises(RuntimeError, match="one-pass normalisation wait gave up"):
         ctx.ws.check_sync()
     assert E.ONEPASS_NORM is False and ctx.ws.sync_error() == 0
@@ -539,6 +541,50 @@ def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
         ref = v.grad
         got = ctx.g[k].cpu()
         assert float((got - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-6 * gmax, k
+
+
+@pytest.mark.parametrize("B,T,h,p,pad", [(2, 61, 128, 0.1, True), (2, 64, 128, 0.3, False), (8, 7, 64, 0.0, True), (2, 9, 128, 0.1, False)])
+def test_ltae_attention_without_stored_weights_is_bit_identical(B, T, h, p, pad):
+    """TimeUNet never reads the post-dropout attention weights (timeunet.py:176-178,204-205): with need_attn=False the
+    register-resident forward stores attn_pre only and the backward re-derives the keep flags from the forward's counter
+    hash.  Same arithmetic on the same values: embedding and EVERY gradient must equal the stored-weights path bit for bit
+    (which the op test above pins to the oracle), with the RNG mask at p > 0 and p = 0, padded frames and T up to 64."""
+    E, L = _engine()
+    g = torch.Generator().manual_seed(29)
+    C = 64
+    sd = _ltae_state(C, g)
+    x = torch.randn(B, T, C, h, h, generator=g)
+    dates = (5 * torch.arange(T)[None] + torch.arange(B)[:, None]).long()
+    valid = torch.ones(B, T, dtype=torch.int32)
+    if pad:
+        tb = max(T - 3, 1)
+        valid[0, tb:] = 0
+        x[0, tb:] = 0
+        dates[0, tb:] = 0
+    g_emb = torch.randn(B, 256, h, h, generator=g).cuda()
+    xd, dd, vd = x.cuda(), dates.cuda(), valid.view(-1).cuda()
+    d = L.LtaeDesc(B, T, C, h * h, 16, 256, 1e-5, p, 77, None, None)
+    assert L.lib().c2s_ltae_attn_optional(ctypes.byref(d)) == 1 and L.lib().c2s_ltae_fwd_path(ctypes.byref(d)) == 2
+    res = []
+    for need in (True, False):
+        ctx = make_ctx({k: v for k, v in sd.items()}, training=True)
+        e_out, a_out = E.ltae_attention(ctx, xd, dd, vd, "te", 16, 4, 256, 1000.0, p, True, 77, None, need_attn=need)
+        assert (a_out is None) == (not need)
+        ctx.tape.grads[e_out.data_ptr()] = g_emb.clone()
+        ctx.tape.backward()
+        torch.cuda.synchronize()
+        res.append((e_out.clone(), ctx.tape.grads[xd.data_ptr()].clone(), {k: v.clone() for k, v in ctx.g.items()}))
+    (e1, gx1, p1), (e0, gx0, p0) = res
+    assert torch.equal(e1, e0) and bool(torch.isfinite(gx1).all())
+    assert torch.equal(gx1, gx0)
+    for k in p1:
+        assert torch.equal(p1[k], p0[k]), k
+    # inference (no tape) without a reader of the masks stores neither tensor
+    ctx = make_ctx({k: v for k, v in sd.items()}, training=False, tape=False)
+    e_inf, a_inf = E.ltae_attention(ctx, xd, dd, vd, "te", 16, 4, 256, 1000.0, p, True, 77, None, need_attn=False)
+    ctx2 = make_ctx({k: v for k, v in sd.items()}, training=False, tape=False)
+    e_ref, a_ref = E.ltae_attention(ctx2, xd, dd, vd, "te", 16, 4, 256, 1000.0, p, True, 77, None)
+    assert a_inf is None and a_ref is not None and torch.equal(e_inf, e_ref)
 
 
 @pytest.mark.parametrize("B,T,C,H,h,pad", [(2, 5, 64, 32, 4, True), (1, 4, 64, 128, 16, False), (2, 3, 128, 16, 16, True)])

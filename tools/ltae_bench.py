@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--C", type=int, default=64)
     ap.add_argument("--hw", type=int, default=128)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-attn", action="store_true", help="TimeUNet's call: nobody reads the post-dropout weights (need_attn=False)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B, T, C, h = a.B, a.T, a.C, a.hw
@@ -33,16 +34,18 @@ def main():
     dates = (5 * torch.arange(T, device=dev)[None]).repeat(B, 1)
     valid = torch.ones(B * T, dtype=torch.int32, device=dev)
     P = B * h * h
-    fwd_bytes = 4.0 * (P * T * C + 2 * 16 * P * T + 256 * P)
-    bwd_bytes = 4.0 * (2 * P * T * C + 3 * 16 * P * T + 256 * P)
+    na = 1 if a.no_attn else 2                      # attention tensors the forward writes
+    fwd_bytes = 4.0 * (P * T * C + na * 16 * P * T + 256 * P)
+    bwd_bytes = 4.0 * (2 * P * T * C + (1 if a.no_attn else 3) * 16 * P * T + 256 * P)
     for rep in range(a.reps):
         grads = {k: torch.empty_like(v) for k, v in sd.items()}
         ctx = E.Ctx(sd, {}, grads, E.Workspace(dev), True, E.Tape())
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        emb, attn = E.ltae_attention(ctx, x, dates, valid, "te", 16, 4, 256, 1000.0, 0.1, True, 1234, None)
+        emb, attn = E.ltae_attention(ctx, x, dates, valid, "te", 16, 4, 256, 1000.0, 0.1, True, 1234, None, need_attn=not a.no_attn)
         e1.record()
-        ctx.tape.grads[attn.data_ptr()] = torch.randn_like(attn)
+        if attn is not None:
+            ctx.tape.grads[attn.data_ptr()] = torch.randn_like(attn)
         ctx.tape.grads[emb.data_ptr()] = torch.randn_like(emb)
         torch.cuda.synchronize()
         e1b = torch.cuda.Event(enable_timing=True)
