@@ -16,6 +16,9 @@
 // pairs: lanes 0..15 of every 16-lane group read/write 64 contiguous bytes.
 #include "common.h"
 
+#define C2S_AS1 __attribute__((address_space(1)))
+#define C2S_AS3 __attribute__((address_space(3)))
+
 namespace {
 
 #ifdef C2S_LT_STAMP
@@ -44,6 +47,13 @@ struct LtaeParams {
     float eps, drop_p;
     uint64_t seed;
     const uint64_t* seed_dev;   // optional device-side step counter added to the seed (hipGraph replay)
+};
+
+// extra outputs of the tiled backward kernels (streaming / register-resident / LDS-resident)
+struct StreamBwd {
+    float* M;        // [P][16][2]  m1, m2
+    float* part_U;   // [tiles][16][C]
+    float* gb64;     // [64-pixel tiles][C][2]  d gamma / d beta partials written by the dx kernel (NULL: the heads kernel wrote part_gb)
 };
 
 // Attention dropout (tae.py:837).  Explicit keep mask [16,P,T] (tests) or a counter-based RNG: ONE 32-bit avalanche hash per
@@ -289,6 +299,209 @@ __global__ __launch_bounds__(256) void ltae_fwd_kernel(LtaeParams p) {
         const f32x4 as4 = *reinterpret_cast<const f32x4*>(ASl + h * 16 + 4 * l4);
         if (pix0 + 4 * l4 < HW)
             *reinterpret_cast<f32x4*>(p.emb + ((size_t)b * NH * DV + h * DV + l15) * HW + pix0 + 4 * l4) = eacc[i4] + as4 * bcv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward, LDS-resident 4-pixel tiles
+// The 16-pixel kernel above launches B*HW/16 workgroups: 64 on the 16 x 16 maps of U-TAE / W-TAE at B = 4 -- a quarter of the
+// chip -- and each of them reads its x tile from global memory three times in dependent chunks (134 us at B=4, T=32, C=128:
+// latency, not bandwidth).  Here a workgroup owns FOUR adjacent pixels: their whole series x[T][C][4] (64 KB at T=32, C=128) is
+// fetched ONCE, by LDS-DMA with every request in flight at the same time, and all phases work on LDS:
+//   0 load        global -> LDS rows [t][c] of one float4 (4 pixels); row pitch per time step C+1 (conflict-free across t)
+//   1 statistics  exact two-pass (mean, then squared deviations) per (pixel, group) over (C/16 x T), padded frames included
+//                 (tae.py:461); thread = (channel, time slice): the group's channels sit in adjacent lanes
+//   2 normalise   xhat = gamma (x - mean) rstd + beta, in place
+//   3 scores      thread = (t, pair of heads): S[t][h][px] = s0 + sum_c U[h][c] xhat[t][c][px]
+//   4 softmax     thread = (px, head, quarter of T): masked softmax over T (tae.py:831), dropout, attn / attn_pre out
+//   5 z           thread = (channel, group of heads): z[h][c][px] = sum_t a[h,t,px] xhat[t][c][px]  -> LDS (over x)
+//   6 emb         16x16x4 MFMA as in the 16-pixel kernel (rows = pixel: 4 of 16 used), + pe and bias terms
+// B*HW/4 workgroups (256 at the bench shape).
+template <int C>
+__global__ __launch_bounds__(256) void ltae_lds_fwd_kernel(LtaeParams p) {
+    extern __shared__ float lds[];
+    constexpr int CP = C + 1;
+    constexpr int NTH = 256 / C, HPT = NH / NTH, CPG = C / NH;
+    const int T = p.T, HW = p.HW;
+    float* xs = lds;                              // [T][CP][4]   x -> xhat;  later z [16][C][4]
+    float* Sl = xs + (size_t)(T * CP > NH * C ? T * CP : NH * C) * 4;     // [T][16][4]   scores -> post-dropout attention
+    float* Ut = Sl + T * 64;                      // [C][16]      U transposed
+    float* ABl = Ut + C * 16;                     // [C][2][4]    scale, shift per (channel, pixel)
+    float* red = ABl + C * 8;                     // [1024]       cross-wave exchanges
+    float* ASl = red + 1024;                      // [16][4]      sum_t attention
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);      // the four tiles that share a 64-byte row segment: same L2
+    const int tiles_per_b = HW / 4;
+    const int b = (int)(tile / tiles_per_b), pix0 = (int)(tile % tiles_per_b) * 4;
+    const long Ptot = (long)p.B * HW;
+    // ---- 0: every row request of the tile in flight at once (T*C / 256 per lane), no registers involved
+    {
+        const float* xb = p.x + (size_t)b * T * C * HW + pix0;
+        const int nrows = T * C;                  // a multiple of 64: a wave's 64 rows never straddle a time step
+        for (int r0 = w * 64; r0 < nrows; r0 += 256) {
+            const int t = r0 / C, c0 = r0 - t * C;
+            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(xb + (size_t)(r0 + lane) * HW),
+                                             (C2S_AS3 void*)(xs + (size_t)(t * CP + c0) * 4), 16, 0, 0);
+        }
+        for (int i = tid; i < C * NH; i += 256) Ut[(i % C) * NH + i / C] = p.U[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- 1: statistics.  thread = (channel c, slice th of the time steps); group = CPG adjacent lanes
+    const int sc_ = tid % C, sth = tid / C;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto group_total = [&](f32x4 v, float* scratch) -> f32x4 {          // sum over the group's channels and the NTH slices
+#pragma unroll
+        for (int o = 1; o < CPG; o <<= 1) {
+            v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+        }
+        if constexpr (NTH == 1) return v;
+        if ((sc_ % CPG) == 0) *reinterpret_cast<f32x4*>(scratch + (sth * NH + sc_ / CPG) * 4) = v;
+        __syncthreads();
+        f32x4 tot = zero4;
+#pragma unroll
+        for (int k = 0; k < NTH; ++k) tot += *reinterpret_cast<const f32x4*>(scratch + (k * NH + sc_ / CPG) * 4);
+        return tot;
+    };
+    f32x4 mean, rstd;
+    {
+        f32x4 s1 = zero4;
+        for (int t = sth; t < T; t += NTH) s1 += *reinterpret_cast<const f32x4*>(xs + (size_t)(t * CP + sc_) * 4);
+        const float inv_n = 1.f / (float)(CPG * T);
+        mean = group_total(s1, red) * inv_n;
+        f32x4 s2 = zero4;
+        for (int t = sth; t < T; t += NTH) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(xs + (size_t)(t * CP + sc_) * 4) - mean;
+            s2 += d * d;
+        }
+        const f32x4 var = group_total(s2, red + 512) * inv_n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rstd[e] = rsqrtf(var[e] + p.eps);
+        if (sth == 0) {
+            const float gm = p.gamma[sc_], bt = p.beta[sc_];
+            const f32x4 a = rstd * gm;
+            *reinterpret_cast<f32x4*>(ABl + sc_ * 8) = a;
+            *reinterpret_cast<f32x4*>(ABl + sc_ * 8 + 4) = bt - mean * a;
+            if ((sc_ % CPG) == 0) {
+                const int g = sc_ / CPG;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p.stats[(((long)b * HW + pix0 + e) * NH + g) * 2] = mean[e];
+                    p.stats[(((long)b * HW + pix0 + e) * NH + g) * 2 + 1] = rstd[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 2: normalise in place (row = tid + 256 k: the lanes of a wave walk adjacent rows)
+    for (int r = tid; r < T * C; r += 256) {
+        const int t = r / C, c = r - t * C;
+        f32x4* xp = reinterpret_cast<f32x4*>(xs + (size_t)(t * CP + c) * 4);
+        *xp = *reinterpret_cast<const f32x4*>(ABl + c * 8) * *xp + *reinterpret_cast<const f32x4*>(ABl + c * 8 + 4);
+    }
+    __syncthreads();
+    // ---- 3: scores.  thread = (t = tid & 31 (+32), heads 2 hg, 2 hg + 1)
+    {
+        const int tl = tid & 31, hg = tid >> 5;
+        for (int t = tl; t < T; t += 32) {
+            const float s00 = p.s0[(b * T + t) * NH + 2 * hg], s01 = p.s0[(b * T + t) * NH + 2 * hg + 1];
+            f32x4 a0 = {s00, s00, s00, s00}, a1 = {s01, s01, s01, s01};
+            const float* xr = xs + (size_t)t * CP * 4;
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c * 4);
+                const float u0 = Ut[c * NH + 2 * hg], u1 = Ut[c * NH + 2 * hg + 1];
+                a0 += xv * u0;
+                a1 += xv * u1;
+            }
+            const bool padded = p.valid != nullptr && p.valid[b * T + t] == 0;
+            const f32x4 m = {-1e6f, -1e6f, -1e6f, -1e6f};                                      // tae.py:831
+            *reinterpret_cast<f32x4*>(Sl + t * 64 + (2 * hg) * 4) = padded ? m : a0;
+            *reinterpret_cast<f32x4*>(Sl + t * 64 + (2 * hg + 1) * 4) = padded ? m : a1;
+        }
+    }
+    __syncthreads();
+    // ---- 4: softmax over T, dropout, outputs.  thread = (px, head, tq): time steps tq, tq + 4, ...
+    {
+        const int hp = tid & 63, tq = tid >> 6, h = hp >> 2, px = hp & 3;
+        const long pidx = (long)b * HW + pix0 + px;
+        float mx = -3.0e38f;
+        for (int t = tq; t < T; t += 4) mx = fmaxf(mx, Sl[t * 64 + hp]);
+        red[tq * 64 + hp] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[hp], red[64 + hp]), fmaxf(red[128 + hp], red[192 + hp]));
+        float den = 0.f;
+        for (int t = tq; t < T; t += 4) {
+            const float e = __expf(Sl[t * 64 + hp] - mx);
+            Sl[t * 64 + hp] = e;
+            den += e;
+        }
+        red[256 + tq * 64 + hp] = den;
+        __syncthreads();
+        den = (red[256 + hp] + red[320 + hp]) + (red[384 + hp] + red[448 + hp]);
+        const float inv_den = 1.f / den;
+        float asum = 0.f;
+        for (int t = tq; t < T; t += 4) {
+            const float a = Sl[t * 64 + hp] * inv_den;
+            const float ad = a * keep_scale(p, h, Ptot, pidx, t);
+            const size_t o = ((size_t)(h * p.B + b) * T + t) * HW + pix0 + px;
+            if (p.attn_pre != nullptr) p.attn_pre[o] = a;
+            p.attn[o] = ad;
+            Sl[t * 64 + hp] = ad;
+            asum += ad;
+        }
+        red[512 + tq * 64 + hp] = asum;
+        __syncthreads();
+        if (tq == 0) ASl[hp] = (red[512 + hp] + red[576 + hp]) + (red[640 + hp] + red[704 + hp]);
+    }
+    if (p.emb == nullptr) return;                 // W-TAE: attention masks only (tae.py:619)
+    // ---- 5: z[h][c][px] = sum_t a[h,t,px] xhat[t][c][px].  thread = (channel, HPT heads)
+    {
+        f32x4 z[HPT];
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) z[k] = zero4;
+#pragma unroll 2
+        for (int t = 0; t < T; ++t) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (size_t)(t * CP + sc_) * 4);
+#pragma unroll
+            for (int k = 0; k < HPT; ++k) z[k] += *reinterpret_cast<const f32x4*>(Sl + t * 64 + (sth * HPT + k) * 4) * xv;
+        }
+        __syncthreads();                          // every thread has read its xhat rows: z takes their place
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) *reinterpret_cast<f32x4*>(xs + (size_t)((sth * HPT + k) * C + sc_) * 4) = z[k];
+        __syncthreads();
+    }
+    // ---- 6: emb[px][16h+j] = sum_c z[h][c][px] Wc[16h+j][c] + sum_t a[h,t,px] pe[t][j] + (sum_t a) bc[16h+j] on the 16x16x4
+    // MFMA: rows = pixel (4 of 16 carry data), columns = j, k = channel / time step; wave w owns heads 4w .. 4w+3
+    {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const bool rowok = l15 < 4;
+        const int rl = rowok ? l15 : 0;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int h = w * 4 + i4;
+            f32x4 acc = zero4;
+            for (int m = 0; m < C / 16; ++m) {
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(p.Wc + (size_t)(h * DV + l15) * C + 16 * m + 4 * l4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float zv = xs[(size_t)(h * C + 16 * m + 4 * l4 + i) * 4 + rl];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowok ? zv : 0.f, wq[i], acc, 0, 0, 0);
+                }
+            }
+            for (int t0 = 0; t0 < T; t0 += 4) {
+                const int t = t0 + l4, tc = t < T ? t : 0;
+                const float av = Sl[tc * 64 + h * 4 + rl];
+                const float pv = p.pe[(size_t)(b * T + tc) * DV + l15];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32((rowok && t < T) ? av : 0.f, pv, acc, 0, 0, 0);
+            }
+            // D: lane (column j = l15, rows 4 l4 + r): pixels 0..3 are rows 0..3 of the lanes with l4 == 0
+            if (l4 == 0) {
+                const float bcv = p.bc[h * DV + l15];
+                const f32x4 as4 = *reinterpret_cast<const f32x4*>(ASl + h * 4);
+                *reinterpret_cast<f32x4*>(p.emb + ((size_t)b * NH * DV + h * DV + l15) * HW + pix0) = acc + as4 * bcv;
+            }
+        }
     }
 }
 
@@ -610,6 +823,265 @@ __global__ __launch_bounds__(256) void ltae_bwd_gx_kernel(LtaeParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, LDS-resident 4-pixel tiles
+// Counterpart of ltae_lds_fwd_kernel: the two kernels above run B*HW/8 workgroups (128 at the bench shape), read x from global
+// memory in three dependent passes (dots, V/Z, dx) and hand GS through HBM.  Here a workgroup owns four pixels, keeps their
+// normalised series xn[T][C][4] in LDS (one LDS-DMA fetch) next to r[16][C][4] and the attention tiles, and does the whole
+// backward of the block:
+//   0 load     x, attn, attn_pre, g_attn, g_emb tiles -> LDS (all requests in flight at once); xn = (x - mean) rstd in place
+//   1 r        r[h][c][px] = sum_j ge[16h+j][px] Wc[16h+j][c]                        thread = (channel, group of heads)
+//   2 dots     dot[h][t] = sum_c r[h][c] (gamma_c xn[t][c] + beta_c)                 thread = (t, pair of heads)
+//   3 softmax  ga = (dot + ge.(bc + pe_t) + g_attn) keep;  gs = a' (ga - sum_t a' ga) thread = (px, head, quarter of T)
+//              d s0 / d bc partials of the tile
+//   4 V, Z     V = sum_t gs xhat (-> d U partial), Z = sum_t attn xhat (-> global, for d Wc)   thread = (channel, heads)
+//   5 dx       d xhat[t][c] = sum_h attn r + gs U; GroupNorm backward with the means m1, m2 over (C/16 x T); d gamma / d beta
+//              partials.  gamma d xhat is parked in gx (each thread re-reads only what it wrote) until the means are known.
+template <int C>
+__global__ __launch_bounds__(256) void ltae_lds_bwd_kernel(LtaeParams p, StreamBwd sb) {
+    extern __shared__ float lds[];
+    constexpr int CP = C + 1;
+    constexpr int NTH = 256 / C, HPT = NH / NTH, CPG = C / NH;
+    const int T = p.T, HW = p.HW;
+    float* xs = lds;                              // [T][CP][4]   x -> xn
+    float* Rl = xs + (size_t)T * CP * 4;          // [16][C][4]   r
+    float* Al = Rl + NH * C * 4;                  // [T][16][4]   attention (post-dropout)
+    float* APl = Al + T * 64;                     // [T][16][4]   attention before dropout
+    float* GAl = APl + T * 64;                    // [T][16][4]   upstream gradient of the attention output
+    float* Dl = GAl + T * 64;                     // [T][16][4]   dots -> ga -> gs
+    float* GEl = Dl + T * 64;                     // [256][4]     tile of g_emb
+    float* GBl = GEl + 1024;                      // [C][2]       gamma, beta
+    float* STl = GBl + 2 * C;                     // [16][2][4]   mean, rstd
+    float* red = STl + 128;                       // [1024]       exchanges
+    float* SUMl = red + 1024;                     // [2][16][4]   sum_t attn, sum_t gs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tiles_per_b = HW / 4;
+    const int b = (int)(tile / tiles_per_b), pix0 = (int)(tile % tiles_per_b) * 4;
+    const long Ptot = (long)p.B * HW;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool has_ge = p.g_emb != nullptr;
+    // ---- 0
+    {
+        const float* xb = p.x + (size_t)b * T * C * HW + pix0;
+        const int nrows = T * C;
+        for (int r0 = w * 64; r0 < nrows; r0 += 256) {
+            const int t = r0 / C, c0 = r0 - t * C;
+            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(xb + (size_t)(r0 + lane) * HW),
+                                             (C2S_AS3 void*)(xs + (size_t)(t * CP + c0) * 4), 16, 0, 0);
+        }
+        // attention tiles: row i = (t, h) -> [16][B][T][HW] row (h, b, t); 64 consecutive i per wave request
+        const int nat = T * NH;
+        for (int i0 = w * 64; i0 < nat; i0 += 256) {
+            const int i = i0 + lane;
+            if (i < nat) {
+                const size_t o = ((size_t)((i & 15) * p.B + b) * T + (i >> 4)) * HW + pix0;
+                __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(p.attn_in + o), (C2S_AS3 void*)(Al + i0 * 4), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(p.attn_pre_in + o), (C2S_AS3 void*)(APl + i0 * 4), 16, 0, 0);
+                if (p.g_attn != nullptr)
+                    __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(p.g_attn + o), (C2S_AS3 void*)(GAl + i0 * 4), 16, 0, 0);
+                else
+                    *reinterpret_cast<f32x4*>(GAl + i * 4) = zero4;
+            }
+        }
+        if (has_ge)
+            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(p.g_emb + ((size_t)b * NH * DV + tid) * HW + pix0),
+                                             (C2S_AS3 void*)(GEl + w * 256), 16, 0, 0);
+        else
+            *reinterpret_cast<f32x4*>(GEl + tid * 4) = zero4;
+        for (int c = tid; c < C; c += 256) { GBl[2 * c] = p.gamma[c]; GBl[2 * c + 1] = p.beta[c]; }
+        if (tid < 128) {                          // (g, mean | rstd, px)
+            const int g = tid >> 3, k = (tid >> 2) & 1, px = tid & 3;
+            STl[tid] = p.stats_in[(((long)b * HW + pix0 + px) * NH + g) * 2 + k];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int r = tid; r < T * C; r += 256) {
+        const int t = r / C, c = r - t * C, g = c / CPG;
+        f32x4* xp = reinterpret_cast<f32x4*>(xs + (size_t)(t * CP + c) * 4);
+        *xp = (*xp - *reinterpret_cast<const f32x4*>(STl + g * 8)) * *reinterpret_cast<const f32x4*>(STl + g * 8 + 4);
+    }
+    // ---- 1: r (zero without an embedding gradient: W-TAE)
+    const int sc_ = tid % C, sth = tid / C;
+#pragma unroll
+    for (int k = 0; k < HPT; ++k) {
+        const int h = sth * HPT + k;
+        f32x4 acc = zero4;
+        if (has_ge) {
+#pragma unroll
+            for (int j = 0; j < DV; ++j)
+                acc += *reinterpret_cast<const f32x4*>(GEl + (h * DV + j) * 4) * p.Wc[(size_t)(h * DV + j) * C + sc_];
+        }
+        *reinterpret_cast<f32x4*>(Rl + (size_t)(h * C + sc_) * 4) = acc;
+    }
+    __syncthreads();
+    // ---- 2: dots
+    {
+        const int tl = tid & 31, hg = tid >> 5;
+        for (int t = tl; t < T; t += 32) {
+            f32x4 d0 = zero4, d1 = zero4;
+            if (has_ge) {
+                const float* xr = xs + (size_t)t * CP * 4;
+                const float* r0 = Rl + (size_t)(2 * hg) * C * 4;
+#pragma unroll 8
+                for (int c = 0; c < C; ++c) {
+                    const f32x4 xh = *reinterpret_cast<const f32x4*>(xr + c * 4) * GBl[2 * c] + GBl[2 * c + 1];
+                    d0 += *reinterpret_cast<const f32x4*>(r0 + c * 4) * xh;
+                    d1 += *reinterpret_cast<const f32x4*>(r0 + (C + c) * 4) * xh;
+                }
+            }
+            *reinterpret_cast<f32x4*>(Dl + t * 64 + (2 * hg) * 4) = d0;
+            *reinterpret_cast<f32x4*>(Dl + t * 64 + (2 * hg + 1) * 4) = d1;
+        }
+    }
+    __syncthreads();
+    // ---- 3: softmax / dropout backward.  thread = (px, head, tq)
+    {
+        const int hp = tid & 63, tq = tid >> 6, h = hp >> 2, px = hp & 3;
+        const long pidx = (long)b * HW + pix0 + px;
+        float ge[DV];
+        float gebc = 0.f;
+#pragma unroll
+        for (int j = 0; j < DV; ++j) {
+            ge[j] = GEl[(h * DV + j) * 4 + px];
+            gebc = fmaf(ge[j], p.bc[h * DV + j], gebc);
+        }
+        float dsum = 0.f, asum = 0.f;
+        for (int t = tq; t < T; t += 4) {
+            float gap = Dl[t * 64 + hp] + gebc + GAl[t * 64 + hp];
+            const f32x4* pe4 = reinterpret_cast<const f32x4*>(p.pe + (size_t)(b * T + t) * DV);
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                const f32x4 pv = pe4[jq];
+                gap = fmaf(ge[4 * jq], pv.x, gap); gap = fmaf(ge[4 * jq + 1], pv.y, gap);
+                gap = fmaf(ge[4 * jq + 2], pv.z, gap); gap = fmaf(ge[4 * jq + 3], pv.w, gap);
+            }
+            const float ga = gap * keep_scale(p, h, Ptot, pidx, t);
+            dsum = fmaf(APl[t * 64 + hp], ga, dsum);
+            Dl[t * 64 + hp] = ga;
+            asum += Al[t * 64 + hp];
+        }
+        red[tq * 64 + hp] = dsum;
+        red[256 + tq * 64 + hp] = asum;
+        __syncthreads();
+        dsum = (red[hp] + red[64 + hp]) + (red[128 + hp] + red[192 + hp]);
+        asum = (red[256 + hp] + red[320 + hp]) + (red[384 + hp] + red[448 + hp]);
+        float gssum = 0.f;
+        for (int t = tq; t < T; t += 4) {
+            const float gs = APl[t * 64 + hp] * (Dl[t * 64 + hp] - dsum);
+            Dl[t * 64 + hp] = gs;
+            gssum += gs;
+            float r = gs;                          // d s0[b,t,h]: sum over the pixels of the tile
+            r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+            if (px == 0) p.part_s0[((size_t)tile * T + t) * NH + h] = r;
+        }
+        red[512 + tq * 64 + hp] = gssum;
+        __syncthreads();
+        if (tq == 0) {
+            SUMl[hp] = asum;
+            SUMl[64 + hp] = (red[512 + hp] + red[576 + hp]) + (red[640 + hp] + red[704 + hp]);
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                float r = ge[j] * asum;
+                r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+                if (px == 0) p.part_bc[(size_t)tile * NH * DV + h * DV + j] = r;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 4: V = sum_t gs xhat (d U partial of the tile), Z = sum_t attn xhat (global: d Wc)
+    const float gm = GBl[2 * sc_], bt = GBl[2 * sc_ + 1];
+    {
+        f32x4 vr[HPT], zr[HPT];
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) { vr[k] = zero4; zr[k] = zero4; }
+#pragma unroll 2
+        for (int t = 0; t < T; ++t) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (size_t)(t * CP + sc_) * 4);
+#pragma unroll
+            for (int k = 0; k < HPT; ++k) {
+                zr[k] += *reinterpret_cast<const f32x4*>(Al + t * 64 + (sth * HPT + k) * 4) * xv;
+                vr[k] += *reinterpret_cast<const f32x4*>(Dl + t * 64 + (sth * HPT + k) * 4) * xv;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) {
+            const int h = sth * HPT + k;
+            const f32x4 zf = zr[k] * gm + *reinterpret_cast<const f32x4*>(SUMl + h * 4) * bt;
+            const f32x4 vf = vr[k] * gm + *reinterpret_cast<const f32x4*>(SUMl + 64 + h * 4) * bt;
+            if (has_ge) *reinterpret_cast<f32x4*>(p.Z + (((size_t)b * NH + h) * C + sc_) * HW + pix0) = zf;
+            sb.part_U[((size_t)tile * NH + h) * C + sc_] = (vf.x + vf.y) + (vf.z + vf.w);
+        }
+    }
+    // ---- 5: d x.  thread = (channel, time slice sth: steps sth, sth + NTH, ...)
+    {
+        auto group_total = [&](f32x4 v, float* scratch) -> f32x4 {
+#pragma unroll
+            for (int o = 1; o < CPG; o <<= 1) {
+                v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+            }
+            if constexpr (NTH == 1) return v;
+            if ((sc_ % CPG) == 0) *reinterpret_cast<f32x4*>(scratch + (sth * NH + sc_ / CPG) * 4) = v;
+            __syncthreads();
+            f32x4 tot = zero4;
+#pragma unroll
+            for (int k = 0; k < NTH; ++k) tot += *reinterpret_cast<const f32x4*>(scratch + (k * NH + sc_ / CPG) * 4);
+            return tot;
+        };
+        const int g = sc_ / CPG;
+        f32x4 r[NH];
+        float u[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            r[h] = *reinterpret_cast<const f32x4*>(Rl + (size_t)(h * C + sc_) * 4);
+            u[h] = p.U[h * C + sc_];
+        }
+        float* gxc = p.gx + (size_t)b * T * C * HW + (size_t)sc_ * HW + pix0;
+        f32x4 dg = zero4, db = zero4, m1 = zero4, m2 = zero4;
+        for (int t = sth; t < T; t += NTH) {
+            f32x4 gxh = zero4;
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                gxh += *reinterpret_cast<const f32x4*>(Al + t * 64 + h * 4) * r[h] + *reinterpret_cast<const f32x4*>(Dl + t * 64 + h * 4) * u[h];
+            const f32x4 xn = *reinterpret_cast<const f32x4*>(xs + (size_t)(t * CP + sc_) * 4);
+            dg += gxh * xn;
+            db += gxh;
+            const f32x4 dxn = gxh * gm;
+            m1 += dxn;
+            m2 += dxn * xn;
+            *reinterpret_cast<f32x4*>(gxc + (size_t)t * C * HW) = dxn;
+        }
+        const float inv_n = 1.f / (float)(CPG * T);
+        __syncthreads();                           // `red` free again (phase 3 read it before its last barrier)
+        m1 = group_total(m1, red) * inv_n;
+        m2 = group_total(m2, red + 256) * inv_n;
+        // d gamma / d beta partial of the tile: sum over its pixels and the time slices
+        const float dgs = (dg.x + dg.y) + (dg.z + dg.w), dbs = (db.x + db.y) + (db.z + db.w);
+        if constexpr (NTH > 1) {
+            red[512 + (sth * C + sc_) * 2] = dgs;
+            red[512 + (sth * C + sc_) * 2 + 1] = dbs;
+            __syncthreads();
+            if (sth == 0) {
+                float a = 0.f, bsum = 0.f;
+#pragma unroll
+                for (int k = 0; k < NTH; ++k) { a += red[512 + (k * C + sc_) * 2]; bsum += red[512 + (k * C + sc_) * 2 + 1]; }
+                p.part_gb[((size_t)tile * C + sc_) * 2] = a;
+                p.part_gb[((size_t)tile * C + sc_) * 2 + 1] = bsum;
+            }
+        } else {
+            p.part_gb[((size_t)tile * C + sc_) * 2] = dgs;
+            p.part_gb[((size_t)tile * C + sc_) * 2 + 1] = dbs;
+        }
+        const f32x4 rstd = *reinterpret_cast<const f32x4*>(STl + g * 8 + 4);
+        for (int t = sth; t < T; t += NTH) {
+            f32x4* gp = reinterpret_cast<f32x4*>(gxc + (size_t)t * C * HW);
+            const f32x4 xn = *reinterpret_cast<const f32x4*>(xs + (size_t)(t * CP + sc_) * 4);
+            *gp = rstd * (*gp - m1 - xn * m2);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ reductions
 // out[grp][k] = sum_{i<count} part[(grp*count + i)*K + k]; one wave per output element, lanes stride the tiles
 // (fixed lane assignment + fixed shuffle tree: bitwise reproducible)
@@ -623,6 +1095,17 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __rest
     for (int i = threadIdx.x; i < count; i += 64) s += part[((size_t)grp * count + i) * K + k];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) out[e] = (float)s;
+}
+
+// the same sum for interleaved (d gamma, d beta) partials [count][C][2], written to two arrays (was: a [C][2] scratch and two
+// strided hipMemcpy2DAsync)
+__global__ __launch_bounds__(64) void reduce_partials_split2_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                                    float* __restrict__ out1, int count, int C) {
+    const int e = blockIdx.x, K = 2 * C;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 64) s += part[(size_t)i * K + e];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) ((e & 1) ? out1 : out0)[e >> 1] = (float)s;
 }
 
 // gU[h,c] = sum_{b,pix} V[b,h,c,pix]     one wave per (h,c)
@@ -1629,11 +2112,6 @@ constexpr int SCH = 4;       // time steps per staged attn / gs chunk
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 
-struct StreamBwd {
-    float* M;        // [P][16][2]  m1, m2
-    float* part_U;   // [tiles][16][C]
-    float* gb64;     // [64-pixel tiles][C][2]  d gamma / d beta partials written by the dx kernel (NULL: the heads kernel wrote part_gb)
-};
 
 __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes of this half of the wave
 #pragma unroll
@@ -2778,6 +3256,23 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
     }
 }
 
+// LDS-resident 4-pixel forward (ltae_lds_fwd_kernel): C in {64, 128, 256}, whole pixel quads, the series of four pixels in LDS
+size_t lds_fwd_bytes(const c2s_ltae_desc* d) {
+    const size_t rows = (size_t)d->T * (d->C + 1) > (size_t)NH * d->C ? (size_t)d->T * (d->C + 1) : (size_t)NH * d->C;
+    return (rows * 4 + (size_t)d->T * 64 + (size_t)d->C * 24 + 1024 + 64) * sizeof(float);
+}
+bool use_lds_fwd(const c2s_ltae_desc* d) {
+    static const bool enabled = [] { const char* e = getenv("C2S_LTAE_LDS"); return !(e && e[0] == '0'); }();
+    return enabled && (d->C == 64 || d->C == 128 || d->C == 256) && d->HW % 4 == 0 && lds_fwd_bytes(d) <= 160 * 1024;
+}
+size_t lds_bwd_bytes(const c2s_ltae_desc* d) {
+    return ((size_t)d->T * (d->C + 1) * 4 + (size_t)NH * d->C * 4 + 4 * (size_t)d->T * 64 + 1024 + 2 * (size_t)d->C + 128 + 1024 + 128) *
+           sizeof(float);
+}
+bool use_lds_bwd(const c2s_ltae_desc* d) {
+    static const bool enabled = [] { const char* e = getenv("C2S_LTAE_LDS_BWD"); return !(e && e[0] == '0'); }();
+    return enabled && (d->C == 64 || d->C == 128 || d->C == 256) && d->HW % 4 == 0 && lds_bwd_bytes(d) <= 160 * 1024;
+}
 size_t fwd_lds(const c2s_ltae_desc* d) {
     const size_t CH = d->C > 64 ? 64 : d->C;
     return ((size_t)d->C * 32 + (size_t)d->T * 256 + 256 + NH * CH * 16) * 4;
@@ -2810,6 +3305,12 @@ void fill(LtaeParams& p, const c2s_ltae_desc* d) {
 
 void init_hook() {
     C2S_RAISE_LDS(ltae_fwd_kernel);
+    C2S_RAISE_LDS(ltae_lds_fwd_kernel<64>);
+    C2S_RAISE_LDS(ltae_lds_fwd_kernel<128>);
+    C2S_RAISE_LDS(ltae_lds_fwd_kernel<256>);
+    C2S_RAISE_LDS(ltae_lds_bwd_kernel<64>);
+    C2S_RAISE_LDS(ltae_lds_bwd_kernel<128>);
+    C2S_RAISE_LDS(ltae_lds_bwd_kernel<256>);
     C2S_RAISE_LDS(ltae_bwd_heads_kernel);
     C2S_RAISE_LDS(ltae_bwd_gx_kernel);
     C2S_RAISE_LDS(ltae_stream_bwd_heads_kernel<4>);
@@ -2908,6 +3409,15 @@ extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, cons
         return C2S_OK;
     }
     c2s_ensure_init();
+    if (use_lds_fwd(d)) {
+        const dim3 grid(d->B * (d->HW / 4));
+        const size_t lb = lds_fwd_bytes(d);
+        if (d->C == 64) hipLaunchKernelGGL(ltae_lds_fwd_kernel<64>, grid, dim3(256), lb, st, p);
+        else if (d->C == 128) hipLaunchKernelGGL(ltae_lds_fwd_kernel<128>, grid, dim3(256), lb, st, p);
+        else hipLaunchKernelGGL(ltae_lds_fwd_kernel<256>, grid, dim3(256), lb, st, p);
+        C2S_CHECK_LAUNCH("ltae_lds_fwd");
+        return C2S_OK;
+    }
     hipLaunchKernelGGL(ltae_fwd_kernel, dim3(d->B * ((d->HW + 15) / 16)), dim3(256), fwd_lds(d), st, p);
     C2S_CHECK_LAUNCH("ltae_fwd");
     return C2S_OK;
@@ -2924,7 +3434,7 @@ extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const f
 //            | part_gb [tiles][C][2]
 extern "C" size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d) {
     if (!d) return 0;
-    const size_t tiles = (size_t)d->B * ((d->HW + 7) / 8);   // upper bound (8-pixel tiles)
+    const size_t tiles = (size_t)d->B * ((d->HW + 3) / 4);   // upper bound (4-pixel tiles)
     return (size_t)NH * d->B * d->T * d->HW + 2 * (size_t)d->B * NH * d->C * d->HW + tiles * d->T * NH + tiles * 256 +
            tiles * d->C * 2;
 }
@@ -2945,9 +3455,10 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     const bool reg_heads = use_reg_bwd(d, g_emb != nullptr);
     C2S_REQUIRE(attn != nullptr || (reg_heads && d->keep == nullptr),
                 "ltae_bwd: attn may only be NULL where the forward could omit it (register-resident path, RNG mask)");
-    const int PT = reg_heads ? RPX : (stream_path ? SPT : bwd_pt(d));
+    const bool lds_path = !stream_path && use_lds_bwd(d);      // fused LDS-resident kernel on 4-pixel tiles (small maps)
+    const int PT = reg_heads ? RPX : (stream_path ? SPT : (lds_path ? 4 : bwd_pt(d)));
     const size_t tiles = (size_t)d->B * ((d->HW + PT - 1) / PT);
-    const size_t tiles_ws = (size_t)d->B * ((d->HW + 7) / 8);
+    const size_t tiles_ws = (size_t)d->B * ((d->HW + 3) / 4);
     LtaeParams p = {};
     fill(p, d);
     p.x = x; p.gamma = gamma; p.beta = beta; p.U = U; p.Wc = Wc; p.bc = bc; p.pe = pe;
@@ -2982,6 +3493,13 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
             hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), lds2, st, p, sb);
         }
         C2S_CHECK_LAUNCH("ltae_stream_bwd_gx");
+    } else if (lds_path) {
+        sb.part_U = p.V;                           // [tiles][16][C] <= the V area [B][16][C][HW]
+        const size_t lb = lds_bwd_bytes(d);
+        if (d->C == 64) hipLaunchKernelGGL(ltae_lds_bwd_kernel<64>, dim3(tiles), dim3(256), lb, st, p, sb);
+        else if (d->C == 128) hipLaunchKernelGGL(ltae_lds_bwd_kernel<128>, dim3(tiles), dim3(256), lb, st, p, sb);
+        else hipLaunchKernelGGL(ltae_lds_bwd_kernel<256>, dim3(tiles), dim3(256), lb, st, p, sb);
+        C2S_CHECK_LAUNCH("ltae_lds_bwd");
     } else {
         hipLaunchKernelGGL(ltae_bwd_heads_kernel, dim3(tiles), dim3(256), bwd1_lds(d), st, p);
         C2S_CHECK_LAUNCH("ltae_bwd_heads");
@@ -2998,16 +3516,12 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(256), dim3(64), 0, st, p.part_bc, gbc, (int)tiles, 256, (long)256);
     C2S_CHECK_LAUNCH("ltae_reduce_bc");
-    {   // interleaved (dgamma, dbeta) -> two outputs: reduce into a [C][2] scratch then split (reuse part_bc tail)
-        float* gb = p.part_bc;   // part_bc is consumed above; 2*C <= 256 floats fit in its first entries
+    {   // interleaved (dgamma, dbeta) partials -> the two outputs
         const int gb_tiles = reg_heads ? d->B * (d->HW / 64) : (int)tiles;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * d->C), dim3(64), 0, st, p.part_gb, gb, gb_tiles,
-                           2 * d->C, (long)2 * d->C);
+        hipLaunchKernelGGL(reduce_partials_split2_kernel, dim3(2 * d->C), dim3(64), 0, st, p.part_gb, ggamma, gbeta, gb_tiles, d->C);
         C2S_CHECK_LAUNCH("ltae_reduce_gb");
-        hipMemcpy2DAsync(ggamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
-        hipMemcpy2DAsync(gbeta, sizeof(float), gb + 1, 2 * sizeof(float), sizeof(float), d->C, hipMemcpyDeviceToDevice, st);
     }
-    if (stream_path) {
+    if (stream_path || lds_path) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(NH * d->C), dim3(64), 0, st, sb.part_U, gU, (int)tiles, NH * d->C,
                            (long)NH * d->C);
     } else {
@@ -3100,12 +3614,8 @@ extern "C" int c2s_pixel_gn_bwd(const float* x, const float* gy, const float* ga
     hipLaunchKernelGGL(pixel_gn_bwd_kernel, dim3(B * groups * chunks), dim3(64), 0, st, x, gy, gamma, stats, gx, workspace,
                        B, C, HW, groups, chunks);
     C2S_CHECK_LAUNCH("pixel_gn_bwd");
-    float* gb = workspace + (size_t)B * chunks * C * 2;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * C), dim3(64), 0, st, workspace, gb, B * chunks, 2 * C,
-                       (long)2 * C);
+    hipLaunchKernelGGL(reduce_partials_split2_kernel, dim3(2 * C), dim3(64), 0, st, workspace, dgamma, dbeta, B * chunks, C);
     C2S_CHECK_LAUNCH("pixel_gn_reduce");
-    hipMemcpy2DAsync(dgamma, sizeof(float), gb, 2 * sizeof(float), sizeof(float), C, hipMemcpyDeviceToDevice, st);
-    hipMemcpy2DAsync(dbeta, sizeof(float), gb + 1, 2 * sizeof(float), sizeof(float), C, hipMemcpyDeviceToDevice, st);
     return C2S_OK;
 }
 
