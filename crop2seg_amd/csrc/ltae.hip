@@ -1789,8 +1789,23 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
     for (int i = 0; i < 8; ++i) {
         const int tc = t0 + i < T ? t0 + i : T - 1;
 #pragma unroll
+#ifdef C2S_LT_COMPUTEONLY
+        for (int s = 0; s < 16; ++s) x[i][s] = __builtin_bit_cast(float, (xoff + (unsigned)(tc * C + s) * 2654435761u) & 0x3fffffffu | 0x30000000u);
+#else
         for (int s = 0; s < 16; ++s) x[i][s] = (xb + (size_t)(tc * C + s) * HW)[xoff];        // uniform row pointer + per-lane offset
+#endif
     }
+#ifdef C2S_LT_LOADONLY
+    {   // diagnostic build: the load phase alone
+        float a_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a_ += x[i][s];
+        if (a_ == 12345.678f) p.stats[0] = a_;
+        return;
+    }
+#endif
     // ---- F2: GroupNorm statistics over (4 channels x T), padded frames included (tae.py:461): exact two-pass moments of the
     // wave's own 4 nt values per group, then ONE exchange: every wave merges the 8 (count, mean, M2) partials with Chan's update
     // in the same order (identical results in all waves, independent of the data).

@@ -173,8 +173,10 @@ def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
         every flip perturbs everything upstream of it, so the deviation grows towards the first layer.
       train mode: the batch-statistics BatchNorm backward is ill-conditioned -- torch's own fp32 gradients sit 1e-3...6e-2
         from an fp64 evaluation (measured again in test_timeunet_streaming_matches_oracle: 2e-2) -- so two
-        valid fp32 evaluations differ at that level; the bar is 3e-2 on the flat gradient (observed 6e-3...1.1e-2), which
-        still catches a wrong kernel (O(1)) or a mishandled padded frame."""
+        valid fp32 evaluations differ at that level and a self-comparison cannot carry a parity bar (round 3 held it to 3e-2
+        and passed with 17 % headroom; a different summation order in one kernel moves it).  Here it is only a sanity bar
+        (1e-1: a wrong kernel or a mishandled padded frame is O(1)); the parity statement for the train-mode gradients of
+        both algorithms is test_train_gradients_of_both_conv_algorithms_vs_fp64_oracle below, anchored on the fp64 oracle."""
     C2S, L, E, Fn, LU, synthetic_batch = _mods()
     x, dates, y, lengths = synthetic_batch(B, T, H, H, 1, "cuda", irregular=lengths is None, lengths=lengths)
     results = {}
@@ -208,7 +210,69 @@ def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
     if mode == "eval":
         assert flat_rel <= 1e-3 and worst[0] <= 5e-3, (flat_rel, worst)
     else:
-        assert flat_rel <= 3e-2 and worst[0] <= 1e-1, (flat_rel, worst)
+        assert flat_rel <= 1e-1 and worst[0] <= 3e-1, (flat_rel, worst)
+
+
+@pytest.mark.parametrize("model", ["utae", "timeunet", "wtae"])
+def test_train_gradients_of_both_conv_algorithms_vs_fp64_oracle(model):
+    """Train-mode gradients at full-resolution planes (128 x 128, padded frames, B = 2 so that the CPU oracle finishes in
+    seconds) for BOTH convolution algorithms -- Winograd (F(2x2,3x3) forward / data / weight gradient, F(2x2,2x2) on the 4x4
+    stride-2 layers) and the direct implicit GEMM -- each against the fp64 oracle with the criterion of SURVEY.md 8c.4:
+    err(impl, fp64) <= max(3 err(oracle fp32, fp64), 1e-3) per tensor for at least 80 % of the tensors, and for every one
+    max(10 err(oracle fp32, fp64), 4e-2) -- 4e-2 is what the reference's own fp32 train-mode gradients move between 1 and 8 CPU
+    threads (1.5-3.6e-2).  Observed: worst tensor 6e-3...1.5e-2, 6-11 % of the tensors above the first bar, for
+    the Winograd AND the direct kernels alike (no input seed keeps the ReLU pre-activations of 128 x 128 planes off the kink,
+    DESIGN.md section 4).  This replaces round 3's 3e-2 bar on the Winograd-vs-direct self-comparison."""
+    C2S, L, E, Fn, LU, _ = _mods()
+    B, T, H = 2, 6, 128
+    cls = {"utae": C2S.UTAE, "timeunet": C2S.TimeUNet_v1, "wtae": C2S.WTAE}[model]
+    ks = [(k, tuple(v.shape)) for k, v in cls(input_dim=10, out_conv=[32, 15]).state_dict().items()]
+    sd = seeded.make_state(ks, 41, "tame")
+    x, dates, y = seeded.make_inputs(B, T, 10, H, H, 7, [6, 4])
+    cfg = O.BackboneConfig(model=model)
+    ref_logits, ref_loss, g32, _ = O.loss_and_grads(sd, x, dates, y, cfg, True)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, _, g64, _ = O.loss_and_grads(sd64, x.double(), dates, y, cfg, True)
+    gmax = max(float(v.norm()) for v in g64.values())
+    old = (E.WINOGRAD, E.S2WINO)
+    try:
+        for wino in (True, False):
+            E.WINOGRAD = wino
+            E.S2WINO = wino
+            net = cls(input_dim=10, out_conv=[32, 15])
+            net.load_state_dict(sd)
+            net = net.cuda().train()
+            net.spec.attn_dropout = 0.0
+            net.spec.mlp_dropout = 0.0
+            step = LU.TrainStep(net, num_classes=15)
+            loss, logits = step(x.cuda(), dates.cuda(), y.cuda(), apply_update=False)
+            assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+            assert float((logits.cpu() - ref_logits).abs().max()) <= 1e-3 * float(ref_logits.abs().max())
+            worst, soft = (0.0, ""), []
+            for n, ref in g64.items():
+                got = step.grads[n].double().cpu()
+                err = float((got - ref).norm())
+                err32 = float((g32[n].double() - ref).norm())
+                sc = float(ref.norm())
+                # hard bar for every tensor; the 8c.4 bar may be missed by a few: 128 x 128 planes put a handful of ReLU
+                # pre-activations within fp32 noise of the kink (no input seed avoids that at this size, DESIGN.md section 4),
+                # and each flip moves everything upstream of it
+                assert err <= max(10 * err32, 4e-2 * sc) + 2e-5 * gmax, (wino, n, err / max(sc, 1e-30), err32 / max(sc, 1e-30))
+                if err > max(3 * err32, 1e-3 * sc) + 2e-5 * gmax:
+                    soft.append((n, err / max(sc, 1e-30), err32 / max(sc, 1e-30)))
+                if sc > 1e-4 * gmax:
+                    worst = max(worst, (err / sc, n))
+            names = list(g64)
+            f64 = torch.cat([g64[n].flatten() for n in names])
+            flat = float((torch.cat([step.grads[n].double().cpu().flatten() for n in names]) - f64).norm() / f64.norm())
+            flat32 = float((torch.cat([g32[n].double().flatten() for n in names]) - f64).norm() / f64.norm())
+            print(f"{model} train, winograd={wino}: flat gradient error vs fp64 {flat:.2e} (oracle fp32: {flat32:.2e}); worst tensor "
+                  f"{worst[0]:.2e} ({worst[1]}); {len(soft)} of {len(g64)} tensors above max(3 err32, 1e-3)")
+            assert flat <= max(5 * flat32, 1e-2), (flat, flat32)
+            assert step.ws.sync_error() == 0
+            del step, net
+    finally:
+        E.WINOGRAD, E.S2WINO = old
 
 
 def test_padded_frames_give_pad_value_features():
