@@ -242,6 +242,8 @@ def utae_forward(ctx, spec, x5, dates, drop):
     for i in range(n_stages - 1):
         f = down_conv_block(ctx, f, f"down_blocks.{i}", spec.encoder_norm, spec, valid, depthwise_separable=dws, add_squeeze=se)
         fmaps.append(f)
+    if ctx.tape is not None and ctx.early_hook is not None:
+        ctx.tape.record(ctx.early_hook)         # in the backward pass: decoder and temporal encoder are done, the encoder follows
     out, att = ltae(ctx, _unfold(fmaps[-1], B, T), dates, valid, "temporal_encoder", spec, drop, True)
     skips = [E.temporal_aggregate(ctx, _unfold(fmaps[-(i + 2)], B, T), att, valid, spec.n_head, spec.agg_mode)
              for i in range(n_stages - 1)]
@@ -256,6 +258,8 @@ def timeunet_forward(ctx, spec, x5, dates, drop):
     se = spec.add_squeeze_excit
     f0 = conv_block(ctx, _fold(x5), "in_conv", 2, spec.encoder_norm, spec, valid, need_input_grad=False, depthwise_separable=dws,
                     add_squeeze=se)
+    if ctx.tape is not None and ctx.early_hook is not None:
+        ctx.tape.record(ctx.early_hook)         # in the backward pass: decoder and temporal encoder are done, the encoder follows
     out, att = ltae(ctx, _unfold(f0, B, T), dates, valid, "temporal_encoder", spec, drop, True, need_attn=ctx.want_att)
     fmaps = [out]
     n_stages = len(spec.encoder_widths)
@@ -279,6 +283,8 @@ def wtae_forward(ctx, spec, x5, dates, drop):
     for i in range(n_stages - 1):
         red = down_conv_block(ctx, red, f"spatial_reduction.{i}", spec.encoder_norm, spec, valid, depthwise_separable=True,
                               add_squeeze=se)
+    if ctx.tape is not None and ctx.early_hook is not None:
+        ctx.tape.record(ctx.early_hook)         # in the backward pass: decoder and temporal encoder are done, the encoder follows
     _, att = ltae(ctx, _unfold(red, B, T), dates, valid, "temporal_encoder", spec, drop, False)
     fmaps = [E.temporal_aggregate(ctx, _unfold(f0, B, T), att, valid, spec.n_head, spec.agg_mode)]
     for i in range(n_stages - 1):

@@ -258,6 +258,7 @@ class Ctx:
         self._packed: Dict[Tuple, Tensor] = {}
         self._plan_ran = False
         self._gwritten: set = set()
+        self.early_hook = None    # TrainStep (data parallel): run by the tape when the backward pass enters the per-frame encoder
         self.want_att = True      # False: the caller never reads the attention masks a forward returns (TrainStep; inference
                                   # without return_att): TimeUNet's full-resolution L-TAE then does not store them
         cus = lib().c2s_device_cus()

@@ -39,9 +39,33 @@ class FlatDataParallel:
             b.copy_(flat[off:off + n].view_as(b).to(b.dtype))
             off += n
 
+    @property
+    def active(self) -> bool:
+        """True when a collective is really issued (world > 1, or the one-GPU rehearsal switch)."""
+        return self.world > 1 or os.environ.get("C2S_BENCH_FORCE_DIST") == "1"
+
+    def reduce_async(self, bucket: torch.Tensor, after=()):
+        """Start the sum of `bucket` (a view of the flat gradient buffer) over ranks while the caller keeps launching the rest
+        of the backward pass.  On HIP tensors the collective is issued from a communication stream that first waits for the
+        caller's current stream and for every stream in `after` (the weight-gradient side stream), so it starts as soon as the
+        bucket's producers have finished and runs next to the encoder's backward pass.  Returns a handle whose wait() orders
+        the caller's current stream (HIP) or the host (gloo) behind the collective; None when no collective is needed."""
+        if not self.active:
+            return None
+        if bucket.is_cuda:
+            comm = getattr(self, "_comm", None)
+            if comm is None:
+                comm = self._comm = torch.cuda.Stream(device=bucket.device)
+            comm.wait_stream(torch.cuda.current_stream(bucket.device))
+            for st in after:
+                comm.wait_stream(st)
+            with torch.cuda.stream(comm):
+                return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def reduce_gradients(self, flat_grad: torch.Tensor) -> float:
         """Sum the flat gradient buffer over ranks in place; returns the scale (1/world) the optimiser must apply
         (folded into the Adam kernel instead of a separate divide pass)."""
-        if self.world > 1 or os.environ.get("C2S_BENCH_FORCE_DIST") == "1":     # the override rehearses the launch on one GPU
+        if self.active and flat_grad.numel() > 0:     # (C2S_BENCH_FORCE_DIST rehearses the launch on one GPU)
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world

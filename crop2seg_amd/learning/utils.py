@@ -16,6 +16,10 @@ from ..backbones.modules import UTAE, WTAE, TimeUNet_v1
 
 Tensor = torch.Tensor
 
+# Two-bucket gradient exchange overlapped with the encoder's backward pass (TrainStep._forward_backward); C2S_DDP_OVERLAP=0
+# keeps the single all-reduce after the backward pass.
+OVERLAP_EXCHANGE = __import__("os").environ.get("C2S_DDP_OVERLAP", "1") != "0"
+
 
 def get_model(config):
     """reference src/learning/utils.py:50-136: dispatch on config.model with the same kwarg mapping
@@ -99,6 +103,7 @@ class TrainStep:
             offs.append(o)
             o += (s + 3) // 4 * 4
         self.total = o
+        self.offsets = offs
         self.flat_param = torch.zeros(o, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(o, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(o, device=dev, dtype=torch.float32)
@@ -130,6 +135,24 @@ class TrainStep:
         tape = E.Tape()
         ctx = E.Ctx(self.params, dict(model.named_buffers()), self.grads, self.ws, model.training, tape)
         ctx.want_att = False                             # the step returns (loss, logits): nobody reads the attention masks
+        self._early, self._early_off = None, 0
+        if (self.dp is not None and self.dp.active and OVERLAP_EXCHANGE and not E.REDUCE_BATCH
+                and not torch.cuda.is_current_stream_capturing()):
+            # Gradient exchange in two buckets: the tape runs this hook once the backward pass has left the decoder
+            # and the temporal encoder -- everything behind the per-frame encoder in the flat buffer is final then -- and that
+            # suffix is summed over the ranks on a communication stream while the encoder's backward pass (the bulk of the
+            # step) still runs; the encoder's own gradients follow after the join.
+            def early_exchange():
+                tape.flush_side()                        # the weight-gradient launches queued so far
+                i = len(self.names)
+                while i > 0 and self.names[i - 1] in ctx._gwritten:
+                    i -= 1
+                if i == 0 or i == len(self.names):
+                    return
+                self._early_off = self.offsets[i]
+                self._early = self.dp.reduce_async(self.flat_grad[self._early_off:],
+                                                   after=(E._side_stream(),) if tape.side_used else ())
+            ctx.early_hook = early_exchange
         out = Fn.FORWARDS[model.spec.model](ctx, model.spec, x, dates, drop)
         logits = out.logits
         loss, glogits = E.cross_entropy(logits, y, self.class_w, self.ws, want_grad=True, label_smoothing=self.label_smoothing)
@@ -186,7 +209,12 @@ class TrainStep:
         loss, logits = self._forward_backward(x.contiguous(), dates.contiguous(), y, drop)
         scale = 1.0
         if self.dp is not None:
-            scale = self.dp.reduce_gradients(self.flat_grad)              # one 4.3 MB bucket per step
+            if self._early is not None:                                   # the decoder's bucket has been under way since the
+                scale = self.dp.reduce_gradients(self.flat_grad[:self._early_off])     # backward pass entered the encoder
+                self._early.wait()
+                self._early = None
+            else:
+                scale = self.dp.reduce_gradients(self.flat_grad)          # one 4.3 MB bucket per step
         if apply_update:
             self.step_count += 1
             E.adam_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,

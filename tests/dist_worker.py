@@ -62,6 +62,27 @@ def main():
     torch.cuda.synchronize()
     if world == 1:
         assert float(lg) == float(lq) and torch.equal(step_d.flat_param, step_p.flat_param), "graph replay with the all-reduce differs"
+    # the exchange must not cost the step anything worth noticing: at the bench shape (U-TAE, B=4, T=32, 128x128) the eager step
+    # with the two-bucket exchange inside a world-size-1 RCCL group against the plain step, same process, interleaved
+    if world == 1 and os.environ.get("C2S_DIST_TIMING", "1") != "0":
+        import time
+        xb, db, yb, _ = synthetic_batch(4, 32, 128, 128, 3, "cuda")
+        net_d2, step_d2 = fresh(True)
+        net_p2, step_p2 = fresh(False)
+        def timed(step, n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step(xb, db, yb)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        for st in (step_d2, step_p2):
+            timed(st, 3)
+        td = min(timed(step_d2, 8) for _ in range(3))
+        tp_ = min(timed(step_p2, 8) for _ in range(3))
+        print(f"DIST_TIMING distributed {td:.3f} ms plain {tp_:.3f} ms", flush=True)
+        assert step_d2._early_off > 0, "the early bucket was never started"
+        assert td <= tp_ + 0.15, f"the world-size-1 exchange costs {td - tp_:.3f} ms per step"
     dist.barrier()
     dist.destroy_process_group()
     print(f"DIST_OK rank {rank} world {world} loss {float(ld):.6f}")

@@ -56,6 +56,15 @@ def _worker(rank, world, port, out_dir):
     flat_g = torch.cat([grads[n].flatten() for n in names])
     local = flat_g.clone()
     scale = dp.reduce_gradients(flat_g)
+    # the two-bucket form TrainStep uses to overlap the exchange with the encoder's backward pass: the suffix (decoder, temporal
+    # encoder, head) starts early as an asynchronous collective, the prefix follows; together they must equal the one-bucket sum
+    two = local.clone()
+    cut = two.numel() // 3
+    work = dp.reduce_async(two[cut:])
+    assert work is not None
+    dp.reduce_gradients(two[:cut])
+    work.wait()
+    assert torch.equal(two, flat_g), "two-bucket exchange differs from the single all-reduce"
     torch.save({"flat_p": flat_p, "local": local, "reduced": flat_g, "scale": scale,
                 "bufs": torch.cat([b.double().flatten() for b in bufs])}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
