@@ -88,6 +88,7 @@ SIGNATURES = {
     "c2s_bf16x3_set_single_product": (None, [I]),
     "c2s_wgrad_workspace_floats": (SZ, [C.POINTER(WgradDesc)]),
     "c2s_conv_wgrad": (I, [C.POINTER(WgradDesc), P, P, P, P, SZ, P, P]),
+    "c2s_wgrad_algorithms": (I, [I, I]),
     "c2s_wgrad_reduce": (I, [C.POINTER(WgradDesc), P, P, L, L, C.POINTER(I), I, P]),
     "c2s_wgrad_reduce_job_bytes": (SZ, []),
     "c2s_wgrad_reduce_job_blocks": (I, [C.POINTER(WgradDesc)]),

@@ -736,13 +736,243 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 4x4 stride-2 pad-1 weight gradient (DownConvBlock, conv.py:263-271) as Winograd F(2x2,2x2) over the four input parities.
+// Over the parities of its input a 4-tap stride-2 filter is two 2-tap stride-1 filters (conv_s2wino.hip):
+//   y[i] = x1[i-1] w0 + x0[i] w1 + x1[i] w2 + x0[i+1] w3,   x0[i] = x[2i], x1[i] = x[2i+1]
+// so per parity pair (py, px) the layer is a 2x2-tap correlation of a parity plane with g = (w[1-py + 2a][1-px + 2b])_{a,b}, and
+//   d U_pp = sum_{2x2 output blocks} (Bt D B) (.) (A dY At),   d g_pp = Gt (d U_pp) G
+// with D the 3x3 patch of the parity plane, dY the 2x2 block of the output gradient and the INTEGER matrices
+// Bt = [[1,-1,0],[0,1,0],[0,-1,1]], G = A = [[1,0],[1,1],[0,1]]: 9 multiplies per (block, channel pair, parity pair) = 36 instead
+// of the direct form's 64, as exact as the direct form.
+// MFMA (32x32x2): D[cin][cout] per transform point, A operand = V (rows = cin, k = block), B operand = Mt (cols = cout).
+// Workgroup = 8 waves on a (32 cin x 64 cout) block: wave (pp, m) owns the 9 points of parity pair pp for cout fragment m
+// (9 accumulators = 144 registers), so d g = Gt dU G is formed in registers and the slabs are the 16-tap slabs of the direct
+// kernel (same reduce kernel).  A spatial tile is 2 x 16 blocks (4 x 32 output pixels, 10 x 66 input pixels, stored as four
+// parity planes of 5 x 33 per channel); both operands are transformed on the fly by the lane that feeds them; the next tile is
+// prefetched into registers under the MFMA loop.
+constexpr int S2W_PL = 5 * 34;                      // one parity plane [5][33 -> 34]
+constexpr int S2W_XP = 4 * S2W_PL + 2;              // input pitch per channel: 682 = 2 * 341 (odd): conflict-free ds_read_b64 across channels
+
+__global__ __launch_bounds__(512) void conv_wgrad_s2wino_kernel(WgradParams p) {
+    constexpr int NTH = 512;
+    constexpr int NXI = 32 * 10 * 16;              // interior float4 items of the raw tile: [10 rows][32 cin][16]
+    constexpr int NXH = 2 * 32 * 10;               // halo scalars
+    constexpr int NG = 64 * 4 * 8;                 // gout float4 items
+    constexpr int XI_PT = NXI / NTH, XH_PT = (NXH + NTH - 1) / NTH, G_PT = NG / NTH;
+    extern __shared__ float lds[];
+    float* Xl = lds;                               // [32 cin][S2W_XP]
+    float* Gl = lds + 32 * S2W_XP;                 // [64 cout][WW_GP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pp = w >> 1, m = w & 1, py = pp >> 1, px = pp & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    const int cb = blockIdx.y * 32, ob = blockIdx.z * 64;
+    const int slice = blockIdx.x;
+    const int Cin = p.C0 + p.C1;
+    const int HWi = p.Hin * p.Win, HWo = p.Hout * p.Wout;
+    const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    f32x4 xi4[XI_PT];
+    float xh[XH_PT];
+    f32x4 gv[G_PT];
+    auto prefetch = [&](int tile) {
+        const int n = tile / (p.tiles_x * p.tiles_y);
+        const int trem = tile - n * (p.tiles_x * p.tiles_y);
+        const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+        const int oy0 = tyi * 4, ox0 = txi * 32;
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HWi;
+        const float* s1n = p.src1 != nullptr ? p.src1 + (size_t)n * p.C1 * HWi : nullptr;
+        const float* gn = p.gout + (size_t)n * p.Cout * HWo;
+#pragma unroll
+        for (int i = 0; i < XI_PT; ++i) {
+            const int e = tid + i * NTH;
+            const int j = e & 15, rr = e >> 4;
+            const int c = rr & 31, r = rr >> 5;
+            int gy = 2 * oy0 - 1 + r;
+            bool ok = true;
+            if (reflect) gy = reflect_idx(gy, p.Hin); else ok = gy >= 0 && gy < p.Hin;
+            const int cg = cb + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && cg < Cin) {
+                const float* sp = cg < p.C0 ? s0n + (size_t)cg * HWi : s1n + (size_t)(cg - p.C0) * HWi;
+                v = *reinterpret_cast<const f32x4*>(sp + (size_t)gy * p.Win + 2 * ox0 + 4 * j);
+            }
+            xi4[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XH_PT; ++i) {
+            const int e = tid + i * NTH;
+            float v = 0.f;
+            if (e < NXH) {
+                const int side = e & 1, rr = e >> 1;
+                const int c = rr & 31, r = rr >> 5;
+                int gy = 2 * oy0 - 1 + r;
+                int gx = side == 0 ? 2 * ox0 - 1 : 2 * ox0 + 64;
+                bool ok = true;
+                if (reflect) { gy = reflect_idx(gy, p.Hin); gx = reflect_idx(gx, p.Win); }
+                else ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                const int cg = cb + c;
+                if (ok && cg < Cin) {
+                    const float* sp = cg < p.C0 ? s0n + (size_t)cg * HWi : s1n + (size_t)(cg - p.C0) * HWi;
+                    v = sp[(size_t)gy * p.Win + gx];
+                }
+            }
+            xh[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int e = tid + i * NTH;
+            const int j = e & 7, rr = e >> 3;
+            const int o = rr & 63, r = rr >> 6;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ob + o < p.Cout) v = *reinterpret_cast<const f32x4*>(gn + (size_t)(ob + o) * HWo + (size_t)(oy0 + r) * p.Wout + ox0 + 4 * j);
+            gv[i] = v;
+        }
+    };
+    // raw row r of the tile = input row 2 oy0 - 1 + r: r even -> odd input rows = plane py 1, row r / 2; r odd -> plane py 0, row
+    // (r - 1) / 2.  Columns alike: input column 2 ox0 - 1 + q: q even -> px 1, q / 2; q odd -> px 0, (q - 1) / 2.
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < XI_PT; ++i) {
+            const int e = tid + i * NTH;
+            const int j = e & 15, rr = e >> 4;
+            const int c = rr & 31, r = rr >> 5;
+            const int ppy = (r & 1) ? 0 : 1, prow = (r & 1) ? (r - 1) >> 1 : r >> 1;
+            float* d0 = Xl + c * S2W_XP + (ppy * 2 + 0) * S2W_PL + prow * 34;       // px 0: q = 4j+1, 4j+3 -> columns 2j, 2j+1
+            float* d1 = Xl + c * S2W_XP + (ppy * 2 + 1) * S2W_PL + prow * 34;       // px 1: q = 4j+2, 4j+4 -> columns 2j+1, 2j+2
+            d0[2 * j] = xi4[i].x; d0[2 * j + 1] = xi4[i].z;
+            d1[2 * j + 1] = xi4[i].y; d1[2 * j + 2] = xi4[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < XH_PT; ++i) {
+            const int e = tid + i * NTH;
+            if (e < NXH) {
+                const int side = e & 1, rr = e >> 1;
+                const int c = rr & 31, r = rr >> 5;
+                const int ppy = (r & 1) ? 0 : 1, prow = (r & 1) ? (r - 1) >> 1 : r >> 1;
+                // left halo: q = 0 -> px 1, column 0;  right halo: q = 65 -> px 0, column 32
+                Xl[c * S2W_XP + (ppy * 2 + (side == 0 ? 1 : 0)) * S2W_PL + prow * 34 + (side == 0 ? 0 : 32)] = xh[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int e = tid + i * NTH;
+            const int j = e & 7, rr = e >> 3;
+            const int o = rr & 63, r = rr >> 6;
+            f32x2w* gd = reinterpret_cast<f32x2w*>(Gl + o * WW_GP + r * 32 + 4 * j);
+            gd[0] = f32x2w{gv[i].x, gv[i].y};
+            gd[1] = f32x2w{gv[i].z, gv[i].w};
+        }
+    };
+    auto next_tile = [&](int tile) {
+        while (tile < p.ntiles) {
+            const int n = tile / (p.tiles_x * p.tiles_y);
+            if (p.valid == nullptr || p.valid[n] != 0) break;
+            tile += p.nslices;
+        }
+        return tile;
+    };
+    // operands of k-step kk: blocks t = 2 kk + lk of the 2 x 16 block tile: the 3 x 3 patch of the wave's parity plane for
+    // channel li, the 2 x 2 block of the output gradient for output channel m * 32 + li
+    const float* xbase = Xl + li * S2W_XP + pp * S2W_PL;
+    const float* gbase = Gl + (m * 32 + li) * WW_GP;
+    auto load_ops = [&](int kk, float (&d)[3][3], f32x2w (&g)[2]) {
+        const int t = 2 * kk + lk;
+        const int by = t >> 4, bx = t & 15;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* pr = xbase + (2 * by + r) * 34 + 2 * bx;
+            const f32x2w v = *reinterpret_cast<const f32x2w*>(pr);
+            d[r][0] = v.x; d[r][1] = v.y; d[r][2] = pr[2];
+        }
+        g[0] = *reinterpret_cast<const f32x2w*>(gbase + (2 * by) * 32 + 2 * bx);
+        g[1] = *reinterpret_cast<const f32x2w*>(gbase + (2 * by + 1) * 32 + 2 * bx);
+    };
+
+    int tile = next_tile((p.nslices & 7) == 0 ? (slice & 7) * (p.nslices >> 3) + (slice >> 3) : slice);
+    if (tile < p.ntiles) prefetch(tile);
+    while (tile < p.ntiles) {
+        const int cand = tile + p.nslices;
+        const int cflag = (p.valid != nullptr && cand < p.ntiles) ? p.valid[cand / (p.tiles_x * p.tiles_y)] : 1;
+        commit();
+        __syncthreads();
+        const int nxt = cflag != 0 ? cand : next_tile(cand + p.nslices);
+        if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
+        float d[2][3][3];
+        f32x2w g[2][2];
+        load_ops(0, d[0], g[0]);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float(&dd)[3][3] = d[kk & 1];
+            const f32x2w(&gg)[2] = g[kk & 1];
+            // V = Bt D B: rows (d0 - d1, d1, d2 - d1), then the same on the columns;  Mt = A dY At: rows (y0, y0 + y1, y1), columns alike
+            float V[3][3], Mt[3][3];
+            {
+                float t[3][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { t[0][c] = dd[0][c] - dd[1][c]; t[1][c] = dd[1][c]; t[2][c] = dd[2][c] - dd[1][c]; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { V[r][0] = t[r][0] - t[r][1]; V[r][1] = t[r][1]; V[r][2] = t[r][2] - t[r][1]; }
+                const f32x2w u1 = gg[0] + gg[1];
+                const f32x2w u[3] = {gg[0], u1, gg[1]};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { Mt[r][0] = u[r].x; Mt[r][1] = u[r].x + u[r].y; Mt[r][2] = u[r].y; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0][0], Mt[0][0], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < 16) load_ops(kk + 1, d[(kk + 1) & 1], g[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 1; i < 9; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[i / 3][i % 3], Mt[i / 3][i % 3], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        tile = nxt;
+    }
+    // ---- d g = Gt dU G in registers: g[a][b] = sum of the 2 x 2 window of dU at (a, b); tap (ky, kx) = (2a + 1 - py, 2b + 1 - px)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int tap = (2 * a + 1 - py) * 4 + (2 * b + 1 - px);
+            float* sl = p.slabs + (((size_t)slice * 16 + tap) * p.CinP + cb) * p.CoutB + ob + m * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (acc[a * 3 + b][r] + acc[a * 3 + b + 1][r]) + (acc[(a + 1) * 3 + b][r] + acc[(a + 1) * 3 + b + 1][r]);
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                sl[(size_t)ci * p.CoutB] = v;
+            }
+        }
+}
+
+int g_wgrad_f23 = -1, g_wgrad_f22 = -1;     // -1: from the environment; 0 / 1: set by c2s_wgrad_algorithms (A/B tests)
+// F(2x2,2x2) path of the 4x4 stride-2 layers on planes that tile into 4 x 32 output pixels (C2S_S2WINO=0 keeps the direct kernel)
+bool s2wino_wgrad(const c2s_wgrad_desc* d) {
+    static const bool env_on = [] { const char* e = getenv("C2S_S2WINO"); const char* e2 = getenv("C2S_S2WINO_WGRAD");
+                                    return !(e && e[0] == '0') && !(e2 && e2[0] == '0'); }();
+    const bool enabled = g_wgrad_f22 >= 0 ? g_wgrad_f22 != 0 : env_on;
+    return enabled && d->KH == 4 && d->KW == 4 && d->S == 2 && d->pad_y == 1 && d->pad_x == 1 && d->Hin == 2 * d->Hout &&
+           d->Win == 2 * d->Wout && d->Wout % 32 == 0 && d->Hout % 4 == 0 && d->C0 + d->C1 >= 32 && d->Cout >= 32 &&
+           d->C0 % 4 == 0;
+}
+
 // Winograd path: wide 3x3 layers on planes that tile into 4 x 32 pixel pieces (C2S_WINOGRAD=0 disables it)
 bool wino_wgrad(const c2s_wgrad_desc* d) {
-    static int enabled = -1;
-    if (enabled < 0) {
+    static int env_on = -1;
+    if (env_on < 0) {
         const char* e = getenv("C2S_WINOGRAD");
-        enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
+        env_on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
+    const int enabled = g_wgrad_f23 >= 0 ? g_wgrad_f23 : env_on;
     return enabled && d->KH == 3 && d->KW == 3 && d->S == 1 && d->pad_y == 1 && d->pad_x == 1 && d->C0 + d->C1 >= 32 &&
            d->Cout >= 32 && d->Win == d->Wout && d->Hin == d->Hout && d->Wout % 32 == 0 && d->Hout % 4 == 0;
 }
@@ -862,10 +1092,17 @@ void init_hook() {
     C2S_RAISE_LDS((conv_wgrad_kernel<1, 1>));
     C2S_RAISE_LDS((conv_wgrad_kernel<4, 2>));
     C2S_RAISE_LDS(conv_wgrad_winograd_kernel<2>);
+    C2S_RAISE_LDS(conv_wgrad_s2wino_kernel);
 }
 C2sInitRegistrar registrar(init_hook);
 
 }  // namespace
+
+extern "C" int c2s_wgrad_algorithms(int winograd_3x3, int winograd_4x4s2) {
+    g_wgrad_f23 = winograd_3x3 < 0 ? -1 : (winograd_3x3 != 0);
+    g_wgrad_f22 = winograd_4x4s2 < 0 ? -1 : (winograd_4x4s2 != 0);
+    return C2S_OK;
+}
 
 extern "C" size_t c2s_wgrad_workspace_floats(const c2s_wgrad_desc* d) {
     if (!d) return 0;
@@ -903,6 +1140,18 @@ extern "C" int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const 
             hipLaunchKernelGGL(conv_wgrad_winograd_kernel<1>, grid, dim3(256), ldsb, st, p);
         }
         C2S_CHECK_LAUNCH("conv_wgrad_winograd");
+        return C2S_OK;
+    }
+    if (s2wino_wgrad(d)) {
+        c2s_ensure_init();
+        p.tiles_x = d->Wout / 32;
+        p.tiles_y = d->Hout / 4;
+        p.ntiles = d->N * p.tiles_x * p.tiles_y;
+        p.log2pc = 5;
+        const size_t ldsb = ((size_t)32 * S2W_XP + (size_t)64 * WW_GP) * sizeof(float);
+        dim3 grid(p.nslices, p.CinP / 32, p.CoutB / 64);
+        hipLaunchKernelGGL(conv_wgrad_s2wino_kernel, grid, dim3(512), ldsb, st, p);
+        C2S_CHECK_LAUNCH("conv_wgrad_s2wino");
         return C2S_OK;
     }
     if (d->KH == 3 && d->S == 1) return launch_wgrad<3, 1>(d, p, st);

@@ -223,6 +223,11 @@ typedef struct c2s_wgrad_desc {
 size_t c2s_wgrad_workspace_floats(const c2s_wgrad_desc* d);
 int c2s_conv_wgrad(const c2s_wgrad_desc* d, const float* src0, const float* src1, const float* gout,
                    float* slabs, size_t slab_floats, const int* valid, void* stream);
+/* Which algorithm c2s_conv_wgrad picks where both apply (process-wide; both forms write the same slabs): winograd_3x3 -- the
+ * Winograd F(2x2,3x3) kernel for wide 3x3 stride-1 layers; winograd_4x4s2 -- the F(2x2,2x2) kernel over the four input parities
+ * for the 4x4 stride-2 layers of DownConvBlock (conv.py:263-271).  1 = on, 0 = the direct split-K kernel, -1 = the default
+ * (on unless C2S_WINOGRAD=0 / C2S_S2WINO=0 in the environment).  For A/B tests of two exact-fp32 evaluations. */
+int c2s_wgrad_algorithms(int winograd_3x3, int winograd_4x4s2);
 int c2s_wgrad_reduce(const c2s_wgrad_desc* d, const float* slabs, float* dst, long stride_o, long stride_c,
                      const int* host_tap_off, int accumulate, void* stream);
 /* All slice sums of a backward pass in one launch: one slab buffer per layer, a table of job records (record size

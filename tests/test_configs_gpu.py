@@ -183,8 +183,9 @@ def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
     old = (E.WINOGRAD, E.S2WINO)
     try:
         for wino in (True, False):
-            E.WINOGRAD = wino            # F(2x2,3x3): the 8-wave / 4-wave kernels and the Winograd weight gradient
+            E.WINOGRAD = wino            # F(2x2,3x3): the 8-wave / 4-wave kernels
             E.S2WINO = wino              # F(2x2,2x2): the 4x4 stride-2 forward and data gradient
+            E.lib().c2s_wgrad_algorithms(int(wino), int(wino))     # ... and both Winograd weight gradients
             net = _model(model, "tame").train(mode == "train")
             net.spec.attn_dropout = 0.0
             net.spec.mlp_dropout = 0.0
@@ -195,6 +196,8 @@ def test_full_size_winograd_vs_direct(cid, model, B, T, H, lengths, mode):
             del step, net
     finally:
         E.WINOGRAD, E.S2WINO = old
+        E.lib().c2s_wgrad_algorithms(-1, -1)
+        E.lib().c2s_wgrad_algorithms(-1, -1)
     (l1, lg1, f1, g1), (l0, lg0, f0, g0) = results[True], results[False]
     flat_rel = float((f1 - f0).double().norm() / f0.double().norm())
     gmax = max(float(g.norm()) for g in g0.values())
@@ -239,6 +242,7 @@ def test_train_gradients_of_both_conv_algorithms_vs_fp64_oracle(model):
         for wino in (True, False):
             E.WINOGRAD = wino
             E.S2WINO = wino
+            E.lib().c2s_wgrad_algorithms(int(wino), int(wino))
             net = cls(input_dim=10, out_conv=[32, 15])
             net.load_state_dict(sd)
             net = net.cuda().train()
@@ -273,6 +277,7 @@ def test_train_gradients_of_both_conv_algorithms_vs_fp64_oracle(model):
             del step, net
     finally:
         E.WINOGRAD, E.S2WINO = old
+        E.lib().c2s_wgrad_algorithms(-1, -1)
 
 
 def test_padded_frames_give_pad_value_features():

@@ -161,6 +161,7 @@ S2WINO_CASES = [
     (2, 32, 128, 64, 64, "reflect"),            # two blocks of output channels
     (1, 8, 72, 24, 80, "reflect"),              # ragged: partial tiles in both directions, padded output channels, 4 chunks
     (2, 10, 64, 16, 64, "zeros"),               # one tile per frame, zero padding
+    (1, 40, 72, 16, 128, "zeros"),              # F(2x2,2x2) weight gradient with a half-empty second input block, padded output channels, zero padding
 ]
 
 
@@ -168,7 +169,8 @@ S2WINO_CASES = [
 def test_conv4x4s2_winograd(case):
     """The F(2x2,2x2) kernels of the 4x4 stride-2 convolution (C2S_S2WINO) against the oracle: forward over the four input
     parities (conv_s2wino.hip) and data gradient per output parity with the reflect adjoint folded in by the variant
-    3-multiply algorithm of the border blocks (conv_s2dgrad.hip); the weight gradient is the direct kernel's."""
+    3-multiply algorithm of the border blocks (conv_s2dgrad.hip); the weight gradient as F(2x2,2x2) over the four input parities
+    (conv_wgrad_s2wino_kernel) where the plane tiles into 4 x 32 output pixels, and -- same inputs -- the direct kernel."""
     E, L = _engine()
     N, Cin, Cout, Hin, Win, mode = case
     g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
@@ -202,6 +204,17 @@ def test_conv4x4s2_winograd(case):
         E.S2WINO = old
     assert rel(ctx.tape.grads[xd.data_ptr()][keep.cuda()], x.grad[keep]) < 5e-6
     assert rel(ctx.g["w"], w.grad) < 5e-6
+    # the other weight-gradient algorithm on the same operands
+    gw1 = ctx.g["w"].clone()
+    try:
+        E.lib().c2s_wgrad_algorithms(-1, 0)
+        ctx._gwritten.discard("w")
+        E._wgrad_launch(ctx, [xd], gfull.cuda(), Cout, Hin // 2, Win // 2, 4, 2, 1, pm, ctx.g["w"], Cin * 16, 16, list(range(16)), 0, valid.cuda())
+    finally:
+        E.lib().c2s_wgrad_algorithms(-1, -1)
+    assert rel(ctx.g["w"], w.grad) < 5e-6
+    fast = Cin >= 32 and (Win // 2) % 32 == 0 and (Hin // 2) % 4 == 0
+    assert torch.equal(gw1, ctx.g["w"]) == (not fast), "the F(2x2,2x2) weight gradient must be the kernel that ran where it applies"
 
 
 def test_weight_gradient_slice_sums_batched():
