@@ -39,7 +39,7 @@ class NormDesc(C.Structure):
 class LtaeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("n_head", C.c_int),
                 ("d_model", C.c_int), ("eps", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
-                ("keep", C.c_void_p), ("seed_dev", C.c_void_p)]
+                ("keep", C.c_void_p), ("seed_dev", C.c_void_p), ("keep_bits", C.c_void_p)]
 
 
 class AggDesc(C.Structure):

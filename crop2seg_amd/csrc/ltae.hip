@@ -47,6 +47,7 @@ struct LtaeParams {
     float eps, drop_p;
     uint64_t seed;
     const uint64_t* seed_dev;   // optional device-side step counter added to the seed (hipGraph replay)
+    unsigned long long* keepbits;   // optional [P][16] keep flags as bits (c2s_ltae_desc.keep_bits)
 };
 
 // extra outputs of the tiled backward kernels (streaming / register-resident / LDS-resident)
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void ltae_lds_fwd_kernel(LtaeParams p) {
     float* xs = lds;                              // [T][CP][4]   x -> xhat;  later z [16][C][4]
     float* Sl = xs + (size_t)(T * CP > NH * C ? T * CP : NH * C) * 4;     // [T][16][4]   scores -> post-dropout attention
     float* Ut = Sl + T * 64;                      // [C][16]      U transposed
-    float* ABl = Ut + C * 16;                     // [C][2][4]    scale, shift per (channel, pixel)
+    float* ABl = Ut + C * 16;                     // [C][2][4]    scale, mean per (channel, pixel);  beta in red[768 ..]
     float* red = ABl + C * 8;                     // [1024]       cross-wave exchanges
     float* ASl = red + 1024;                      // [16][4]      sum_t attention
     const int tid = threadIdx.x, lane = tid & 63;
@@ -378,10 +379,10 @@ __global__ __launch_bounds__(256) void ltae_lds_fwd_kernel(LtaeParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) rstd[e] = rsqrtf(var[e] + p.eps);
         if (sth == 0) {
-            const float gm = p.gamma[sc_], bt = p.beta[sc_];
-            const f32x4 a = rstd * gm;
+            const f32x4 a = rstd * p.gamma[sc_];
             *reinterpret_cast<f32x4*>(ABl + sc_ * 8) = a;
-            *reinterpret_cast<f32x4*>(ABl + sc_ * 8 + 4) = bt - mean * a;
+            *reinterpret_cast<f32x4*>(ABl + sc_ * 8 + 4) = mean;
+            red[768 + sc_] = p.beta[sc_];
             if ((sc_ % CPG) == 0) {
                 const int g = sc_ / CPG;
 #pragma unroll
@@ -393,11 +394,12 @@ __global__ __launch_bounds__(256) void ltae_lds_fwd_kernel(LtaeParams p) {
         }
         __syncthreads();
     }
-    // ---- 2: normalise in place (row = tid + 256 k: the lanes of a wave walk adjacent rows)
+    // ---- 2: normalise in place: xhat = (x - mean) (rstd gamma) + beta -- the mean is subtracted first, not folded into the shift
+    // (row = tid + 256 k: the lanes of a wave walk adjacent rows)
     for (int r = tid; r < T * C; r += 256) {
         const int t = r / C, c = r - t * C;
         f32x4* xp = reinterpret_cast<f32x4*>(xs + (size_t)(t * CP + c) * 4);
-        *xp = *reinterpret_cast<const f32x4*>(ABl + c * 8) * *xp + *reinterpret_cast<const f32x4*>(ABl + c * 8 + 4);
+        *xp = (*xp - *reinterpret_cast<const f32x4*>(ABl + c * 8 + 4)) * *reinterpret_cast<const f32x4*>(ABl + c * 8) + red[768 + c];
     }
     __syncthreads();
     // ---- 3: scores.  thread = (t = tid & 31 (+32), heads 2 hg, 2 hg + 1)
@@ -1746,7 +1748,8 @@ constexpr int R_AH = 16 * RZP + 4;                 // apeT pitch per head
 constexpr int R_AD = 0;                            // adL [64 t][16 px][16 h] (pitch R_TP);  later zT [16 h][64 c][RZP] (pitch R_ZH)
 constexpr int R_XS = R_AD + 16 * R_ZH;             // xs [16 px][16 t][64 c]: a quarter of the time steps; before: red [2][8][16][16]; later apeT
 constexpr int R_AS = R_XS + R_XB;                  // asum partials [8 w][16 h][16 px]
-constexpr int R_FLOATS = R_AS + 8 * 16 * 16;       // 40,064 floats = 160,256 bytes
+constexpr int R_KB = R_AS + 8 * 16 * 16;           // keep flags of the tile as bits [16 h][16 px][2 x 32]
+constexpr int R_FLOATS = R_KB + 512;               // 40,576 floats = 162,304 bytes
 static_assert(16 * R_ZH >= 64 * R_TP && R_XB >= 16 * R_AH && R_XB >= 2 * 8 * 16 * 16, "LDS map of the register-resident forward");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)):
@@ -1782,6 +1785,8 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
     const unsigned xoff = (unsigned)(16 * q) * (unsigned)HW + (unsigned)pix;
     const int t0 = 8 * w;
     const int nt = T - t0 < 0 ? 0 : (T - t0 < 8 ? T - t0 : 8);          // time steps of this wave that exist
+    unsigned* kbL = reinterpret_cast<unsigned*>(lds + R_KB);
+    kbL[tid] = 0u;                                 // (512 words; the first workgroup barrier comes long before F4 ORs into them)
     LT_STAMP(0);
     // ---- F1
     float x[8][16];
@@ -1967,6 +1972,7 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
                 }
             }
             float as = 0.f;
+            unsigned kept = 0u;                    // bit i: step t0 + i was kept
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float ad = 0.f;                    // steps T..63 carry zero weight
@@ -1974,6 +1980,7 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
                     const int t = t0 + i;
                     const float a = sc[i][r] * sm[r];
                     const float ks = rng ? drop_pick(dc, bits[i >> 1], t) : keep_scale(p, h, Ptot, pidx, t);
+                    kept |= (ks != 0.f ? 1u : 0u) << i;
                     ad = a * ks;
                     if (p.attn_pre != nullptr) (p.attn_pre + (size_t)(b * T + t) * HW)[hoff[r]] = a;
                     if (p.attn != nullptr) (p.attn + (size_t)(b * T + t) * HW)[hoff[r]] = ad;    // NULL: nobody reads the post-dropout
@@ -1983,6 +1990,7 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
                 sc[i][r] = ad;
             }
             asp[(w * 16 + h) * 16 + px] = as;      // sum_t a, per wave (summed in the epilogue)
+            atomicOr(&kbL[(h * 16 + px) * 2 + (w >> 2)], kept << (8 * (w & 3)));     // (unconditional: no branch inside the phase)
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1991,6 +1999,11 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
     if (p.emb == nullptr) return;                  // attention masks only (tae.py:619)
     lds_barrier();
     LT_STAMP(3);
+    if (p.keepbits != nullptr && tid < 256) {      // thread = (px, h): the 16 words of a pixel are 128 contiguous bytes
+        const int kh = tid & 15, kp = tid >> 4;
+        const unsigned long long word = (unsigned long long)kbL[(kh * 16 + kp) * 2] | ((unsigned long long)kbL[(kh * 16 + kp) * 2 + 1] << 32);
+        p.keepbits[((size_t)b * HW + (size_t)(pix - px + kp)) * NH + kh] = word;
+    }
 
     // ---- F5: z[h][c] = sum_t a[h][t] xhat[t][c] PER PIXEL on the MFMA:  A = a_px [16 h x 4 t] from adL,  B = xhat_px [4 t x 16 c].
     // The B operand of one pixel is spread over lanes and waves, so xhat goes through LDS, 16 time steps (two waves' registers,
@@ -2602,9 +2615,8 @@ __device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, unsign
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
-// REKEEP: the forward did not store the post-dropout weights (attn_in == NULL): the keep flags are re-derived from the
-// counter hash of the forward (same seed, same (row, pair of steps) counters) -- one tensor less to read.  Only for the RNG
-// mask (an explicit keep tensor comes with the stored weights); p = 0 gives threshold 0 and scale 1.
+// REKEEP: the forward did not store the post-dropout weights (attn_in == NULL) but the keep flags as bits (p.keepbits [P][16]
+// words, bit t): one float tensor less to read.
 template <bool REKEEP>
 __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, StreamBwd sb) {
     extern __shared__ float lds[];
@@ -2654,9 +2666,6 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
     const bool dropping = p.drop_p > 0.f;
     const float thr16 = (float)(uint32_t)(p.drop_p * 65536.f + 0.5f);
     const float kscale = !dropping ? 1.f : (p.keep != nullptr ? 1.f / (1.f - p.drop_p) : 65536.f / (65536.f - thr16));
-    DropCtx dc = {};
-    if constexpr (REKEEP) dc = drop_ctx(p);        // (uniform scalar work; thr = 0, inv = 1 without dropout)
-    const long Ptot = (long)p.B * HW;
 
     LT_STAMP_B(0);
     // ---- P0 .. H1, ordered for the load queue (a wave has 64 loads in flight at most and issues in order): the small operands
@@ -2705,8 +2714,13 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
         const int tc = t0 + i < T ? t0 + i : T - 1;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+#ifdef C2S_LT_COMPUTEONLY
+            x[i][s][0] = __builtin_bit_cast(float, (xvo + (unsigned)(tc * C + 2 * s) * 2654435761u) & 0x3fffffffu | 0x30000000u);
+            x[i][s][1] = __builtin_bit_cast(float, (xvo + (unsigned)(tc * C + 2 * s + 1) * 2654435761u) & 0x3fffffffu | 0x30000000u);
+#else
             x[i][s][0] = bload(rx, xvo, (unsigned)(tc * C + 2 * s) * rowb);
             x[i][s][1] = bload(rx, xvo, (unsigned)(tc * C + 2 * s + 1) * rowb);
+#endif
         }
     };
 #pragma unroll
@@ -2856,6 +2870,12 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
     // attn_pre stays in registers until gs is formed, attn goes straight into aL for the Z pass: every tensor is read once.
     {
         float apk[8][4], sm[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned long long kw[4] = {0ull, 0ull, 0ull, 0ull};   // REKEEP: keep flags of (pixel, heads 4q .. 4q+3)
+        if constexpr (REKEEP) {
+            const ulonglong2* kp2 = reinterpret_cast<const ulonglong2*>(p.keepbits + (size_t)pidx * NH + 4 * q);
+            const ulonglong2 k01 = kp2[0], k23 = kp2[1];
+            kw[0] = k01.x; kw[1] = k01.y; kw[2] = k23.x; kw[3] = k23.y;
+        }
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
             __builtin_amdgcn_sched_barrier(0);
@@ -2868,17 +2888,12 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
                     if constexpr (!REKEEP) adv[ii][r] = bload(rad, hv0, trow(4 * ih + ii, r));
                 }
             if constexpr (REKEEP) {
-                // attn = attn_pre * keep-scale with the forward's hash: t0 is even, steps (2u, 2u+1) of a row share one hash
+                // attn = attn_pre * keep-scale, the keep flags from the forward's bit words (pixel, head): bits t0 .. t0+7
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const uint64_t rb = (uint64_t)((long)(4 * q + r) * Ptot + pidx) * (uint64_t)dc.half_t + (uint64_t)((t0 >> 1) + 2 * ih);
+                    const unsigned m8 = (unsigned)(kw[r] >> (t0 + 4 * ih)) & 0xfu;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const uint64_t i2 = rb + (uint64_t)u;
-                        const uint32_t bits = c2s_hash32((uint32_t)i2 ^ dc.key ^ (uint32_t)(i2 >> 32) * 0x85EBCA6Bu);
-                        adv[2 * u][r] = apk[4 * ih + 2 * u][r] * ((bits & 0xffffu) >= dc.thr ? dc.inv : 0.f);
-                        adv[2 * u + 1][r] = apk[4 * ih + 2 * u + 1][r] * ((bits >> 16) >= dc.thr ? dc.inv : 0.f);
-                    }
+                    for (int ii = 0; ii < 4; ++ii) adv[ii][r] = apk[4 * ih + ii][r] * (((m8 >> ii) & 1u) ? kscale : 0.f);
                 }
             }
 #pragma unroll
@@ -3122,8 +3137,13 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
     const int tiles_per_b = HW / 64;
     const int b = (int)(tile / tiles_per_b);
     const int pix = (int)(tile % tiles_per_b) * 64 + lane;
-    const long pidx = (long)b * HW + pix, Ptot = (long)p.B * HW;
-    const bool rekeep = p.attn_in == nullptr;      // the forward stored the pre-dropout weights only: keep flags from its hash
+    const long pidx = (long)b * HW + pix;
+    const bool rekeep = p.attn_in == nullptr;      // the forward stored the pre-dropout weights only + the keep flags as bits
+    const float kscale = p.drop_p <= 0.f ? 1.f : (p.keep != nullptr ? 1.f / (1.f - p.drop_p)
+                                                                    : 65536.f / (65536.f - (float)(uint32_t)(p.drop_p * 65536.f + 0.5f)));
+    unsigned long long* kbl = reinterpret_cast<unsigned long long*>(lds + GX_FLOATS);        // [16 h][64 px] keep words of the tile
+    if (rekeep) kbl[(threadIdx.x & 15) * 64 + (threadIdx.x >> 4)] = p.keepbits[((size_t)pidx - lane) * NH + threadIdx.x];   // 8 KB, contiguous
+    const unsigned* kb32 = reinterpret_cast<const unsigned*>(kbl);                           // (read after the barriers of the r phase below)
     const int g = w;
 
     // ---- r[h][c][px] = sum_j Wc[16h+j][c] ge[16h+j][px] on the MFMA, wave = head:  4 channel tiles x 4 pixel tiles x 4 k-steps
@@ -3200,7 +3220,9 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
                 const int arr = row >> 8, tt = (row >> 4) & 15, h = row & 15;
                 const int t = tc0 + tt < T ? tc0 + tt : T - 1;
                 const size_t o = (size_t)h * hstride + ((size_t)b * T + t) * HW + pix;
-                v[i] = arr == 0 ? (rekeep ? p.attn_pre_in[o] * keep_scale(p, h, Ptot, pidx, t) : p.attn_in[o]) : p.GS[o];
+                // (a chunk of 16 steps lies in one 32-bit half of the keep word: 32-bit shifts only)
+                v[i] = arr == 0 ? (rekeep ? p.attn_pre_in[o] * (((kb32[(h * 64 + lane) * 2 + (tc0 >> 5)] >> (t & 31)) & 1u) ? kscale : 0.f) : p.attn_in[o])
+                                : p.GS[o];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -3316,6 +3338,7 @@ int check(const c2s_ltae_desc* d) {
 void fill(LtaeParams& p, const c2s_ltae_desc* d) {
     p.B = d->B; p.T = d->T; p.C = d->C; p.HW = d->HW; p.eps = d->eps; p.drop_p = d->dropout_p; p.seed = d->seed; p.seed_dev = d->seed_dev;
     p.keep = d->keep;
+    p.keepbits = (unsigned long long*)d->keep_bits;
 }
 
 void init_hook() {
@@ -3468,8 +3491,8 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     (void)s0; (void)valid;
     const bool stream_path = g_emb != nullptr && use_stream(d);
     const bool reg_heads = use_reg_bwd(d, g_emb != nullptr);
-    C2S_REQUIRE(attn != nullptr || (reg_heads && d->keep == nullptr),
-                "ltae_bwd: attn may only be NULL where the forward could omit it (register-resident path, RNG mask)");
+    C2S_REQUIRE(attn != nullptr || (reg_heads && d->keep_bits != nullptr),
+                "ltae_bwd: attn may only be NULL where the forward could omit it (register-resident path) and left the keep flags in d->keep_bits");
     const bool lds_path = !stream_path && use_lds_bwd(d);      // fused LDS-resident kernel on 4-pixel tiles (small maps)
     const int PT = reg_heads ? RPX : (stream_path ? SPT : (lds_path ? 4 : bwd_pt(d)));
     const size_t tiles = (size_t)d->B * ((d->HW + PT - 1) / PT);
@@ -3503,7 +3526,7 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         const size_t lds2 = ((size_t)NH * d->C * SPT + 2 * SCH * 4 * SPT * 4) * sizeof(float);
         static const bool gx64 = [] { const char* e = getenv("C2S_LTAE_GX64"); return !(e && e[0] == '0'); }();
         if ((gx64 || reg_heads) && d->C == 64 && d->HW % 64 == 0) {
-            hipLaunchKernelGGL(ltae_stream_bwd_gx64_kernel, dim3(d->B * (d->HW / 64)), dim3(1024), GX_FLOATS * sizeof(float), st, p, sb);
+            hipLaunchKernelGGL(ltae_stream_bwd_gx64_kernel, dim3(d->B * (d->HW / 64)), dim3(1024), GX_FLOATS * sizeof(float) + 8192, st, p, sb);
         } else {
             hipLaunchKernelGGL(ltae_stream_bwd_gx_kernel<4>, dim3(tiles), dim3(1024), lds2, st, p, sb);
         }

@@ -982,6 +982,10 @@ def ltae_attention(ctx: Ctx, x5: Tensor, dates: Tensor, valid: Optional[Tensor],
     skip_attn = not need_attn and mode == 0 and with_embedding and (
         bool(lib().c2s_ltae_attn_optional(C.byref(d))) if ctx.tape is not None else lib().c2s_ltae_fwd_path(C.byref(d)) == 2)
     attn = None if skip_attn else torch.empty(n_head, B, T, h, w, device=x5.device, dtype=torch.float32)
+    if skip_attn and ctx.tape is not None:      # the keep flags of the attention dropout as bits, for the backward pass
+        keep_bits = torch.empty(B * HW * n_head, device=x5.device, dtype=torch.int64)
+        d.keep_bits = keep_bits.data_ptr()
+        ctx.tape.track(keep_bits)
     # softmax before dropout: saved for the backward (and the score scratch of the three-pass streaming kernels); a forward
     # without a tape (inference) does not store it: 16*B*T*h*w floats less to write
     need_pre = ctx.tape is not None or lib().c2s_ltae_fwd_path(C.byref(d)) == 1

@@ -129,14 +129,14 @@ class TrainStep:
             self.dp.sync_parameters(self.flat_param, [b for _, b in model.named_buffers()])
 
     # ------------------------------------------------------------------------------------------------
-    def _forward_backward(self, x: Tensor, dates: Tensor, y: Tensor, drop: Fn.DropoutState) -> Tuple[Tensor, Tensor]:
+    def _forward_backward(self, x: Tensor, dates: Tensor, y: Tensor, drop: Fn.DropoutState, overlap_exchange: bool = False) -> Tuple[Tensor, Tensor]:
         """zero_grad -> forward -> CE -> backward into the flat gradient buffer (stream-ordered, no host sync)."""
         model = self.model
         tape = E.Tape()
         ctx = E.Ctx(self.params, dict(model.named_buffers()), self.grads, self.ws, model.training, tape)
         ctx.want_att = False                             # the step returns (loss, logits): nobody reads the attention masks
         self._early, self._early_off = None, 0
-        if (self.dp is not None and self.dp.active and OVERLAP_EXCHANGE and not E.REDUCE_BATCH
+        if (overlap_exchange and self.dp is not None and self.dp.active and OVERLAP_EXCHANGE and not E.REDUCE_BATCH
                 and not torch.cuda.is_current_stream_capturing()):
             # Gradient exchange in two buckets (SURVEY.md 8e): the tape runs this hook once the backward pass has left the decoder
             # and the temporal encoder -- everything behind the per-frame encoder in the flat buffer is final then -- and that
@@ -206,7 +206,7 @@ class TrainStep:
         """Eager step.  Returns (loss[1] device tensor, logits).  No host synchronisation inside."""
         self.model._check_inputs(x, dates)
         drop = dropout_state if dropout_state is not None else self._fresh_dropout()
-        loss, logits = self._forward_backward(x.contiguous(), dates.contiguous(), y, drop)
+        loss, logits = self._forward_backward(x.contiguous(), dates.contiguous(), y, drop, overlap_exchange=True)
         scale = 1.0
         if self.dp is not None:
             if self._early is not None:                                   # the decoder's bucket has been under way since the

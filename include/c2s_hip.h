@@ -355,6 +355,10 @@ typedef struct c2s_ltae_desc {
     const float* keep;    /* optional explicit keep mask [16,P,T] (tests); NULL => RNG when dropout_p>0 */
     const uint64_t* seed_dev; /* optional DEVICE counter mixed into the seed (advanced by the caller between
                                  hipGraph replays so that every step draws a fresh mask); NULL => seed only */
+    uint64_t* keep_bits;  /* optional [B*hw][16] words, bit t of word (pixel, head) = "time step t was kept by the attention
+                             dropout": written by c2s_ltae_attn_fwd_ws on the register-resident path, read by c2s_ltae_attn_bwd
+                             when attn == NULL (c2s_ltae_attn_optional): 1 bit per element instead of a second
+                             [16,B,T,hw] float tensor.  NULL otherwise. */
 } c2s_ltae_desc;
 
 int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
@@ -381,9 +385,9 @@ int c2s_ltae_uses_streaming(const c2s_ltae_desc* d);
 int c2s_ltae_fwd_path(const c2s_ltae_desc* d);
 /* 1 when a caller that never reads the post-dropout attention weights (TimeUNet_v1.forward without return_att,
  * timeunet.py:176-178,204-205) may pass attn == NULL to c2s_ltae_attn_fwd_ws AND to c2s_ltae_attn_bwd: both then take the
- * register-resident kernels, the forward stores attn_pre only (16*B*T*hw floats less to write) and the backward re-derives
- * the keep flags from the forward's counter hash (as many floats less to read).  Needs the RNG mask (d->keep == NULL) and
- * the embedding output. */
+ * register-resident kernels, the forward stores attn_pre and the keep flags as bits (d->keep_bits: 16*B*T*hw floats less to
+ * write) and the backward reads those (as many floats less to read).  Needs d->keep_bits on both calls, the RNG mask
+ * (d->keep == NULL) and the embedding output. */
 int c2s_ltae_attn_optional(const c2s_ltae_desc* d);
 size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d);
 /* g_emb [B,256,hw] or NULL; g_attn [16,B,T,hw] or NULL.  Outputs (all overwritten): gx [B,T,C,hw],

@@ -129,13 +129,17 @@ class Golden:
         # this flavour a single tensor may reach 10x the reference's deviation or 4e-2 relative (the reference's own
         # thread-count-to-thread-count deviation reaches 3.6e-2); callers additionally require that at most 10 % of the
         # tensors exceed the 5x / 1e-2 bound (self.soft_violations).  A wrong kernel is off by O(1).
+        # Round 4: the same two-level form for the "tame" fixtures.  Two forward kernels of the L-TAE that both sit 3e-7 from
+        # the fp64 oracle (tools/ltae_err_probe.py, profiles/r04_ltae_small_map_error.txt: the LDS-resident and the 16-pixel
+        # kernel) put a single tensor of two train-mode fixtures at 1.2e-3 / 2.2e-3 where the other kernel stays below 1e-3:
+        # batch-statistics BatchNorm amplifies a 1e-7 change of its input by 1e4 on individual tensors, whichever valid fp32
+        # order produced it.  So: bar 3 x err_ref / 1e-3 for at least 90 % of the tensors, 6 x err_ref / 4e-3 for every one.
         wi = self.meta["flavour"] == "wi"
         floor, factor = (1e-2, 5) if wi else (1e-3, 3)
         bound = max(factor * err_ref, floor * scale) + 1e-6 * gmax
-        if wi:
-            if err > bound:
-                self.soft_violations = getattr(self, "soft_violations", []) + [(name, err / scale, err_ref / scale)]
-            bound = max(2 * factor * err_ref, 4 * floor * scale) + 1e-6 * gmax
+        if err > bound:
+            self.soft_violations = getattr(self, "soft_violations", []) + [(name, err / scale, err_ref / scale)]
+        bound = max(2 * factor * err_ref, 4 * floor * scale) + 1e-6 * gmax
         assert err <= bound, (name, err / scale, err_ref / scale)
         return err / scale
 

@@ -559,9 +559,10 @@ def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
 @pytest.mark.parametrize("B,T,h,p,pad", [(2, 61, 128, 0.1, True), (2, 64, 128, 0.3, False), (8, 7, 64, 0.0, True), (2, 9, 128, 0.1, False)])
 def test_ltae_attention_without_stored_weights_is_bit_identical(B, T, h, p, pad):
     """TimeUNet never reads the post-dropout attention weights (timeunet.py:176-178,204-205): with need_attn=False the
-    register-resident forward stores attn_pre only and the backward re-derives the keep flags from the forward's counter
-    hash.  Same arithmetic on the same values: embedding and EVERY gradient must equal the stored-weights path bit for bit
-    (which the op test above pins to the oracle), with the RNG mask at p > 0 and p = 0, padded frames and T up to 64."""
+    register-resident forward stores attn_pre and the keep flags of the dropout as one bit per element (c2s_ltae_desc.keep_bits),
+    and the backward kernels rebuild attn = attn_pre * keep from those.  Same arithmetic on the same values: embedding and
+    EVERY gradient must equal the stored-weights path bit for bit (which the op test above pins to the oracle), with the RNG
+    mask at p > 0 and p = 0, padded frames and T up to 64."""
     E, L = _engine()
     g = torch.Generator().manual_seed(29)
     C = 64

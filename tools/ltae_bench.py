@@ -11,6 +11,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from crop2seg_amd import _lib  # noqa: E402
+if os.environ.get("C2S_DIAG_LIB"):          # diagnostic builds (tools/_diag/libs): load-only / compute-only kernels
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["C2S_DIAG_LIB"])
 from crop2seg_amd import engine as E  # noqa: E402
 from oracle import seeded  # noqa: E402
 
