@@ -103,6 +103,9 @@ class Workspace:
         plan = self.reduce_plan
         if plan is None or plan["key"] != key:
             if torch.cuda.is_current_stream_capturing():
+                import warnings
+                warnings.warn("crop2seg_amd: the batched weight-gradient slice sum has no job table for this capture (the warm-up "
+                              "pass ran other layers or buffers): falling back to one launch per layer inside the graph")
                 for (dbytes, slabs_ptr, dst_ptr, so, sc, taps, acc, d) in jobs:
                     check(L_.c2s_wgrad_reduce(C.byref(d), slabs_ptr, dst_ptr, so, sc, _tap_array(taps), acc, _stream()), "wgrad_reduce")
                 return
@@ -114,6 +117,11 @@ class Workspace:
                                                    _tap_array(taps), acc, block), "wgrad_reduce_job_fill")
                 block += L_.c2s_wgrad_reduce_job_blocks(C.byref(d))
             plan = self.reduce_plan = {"key": key, "table": table.to(self.device), "njobs": len(jobs), "blocks": block}
+            # one slab buffer per weight lives as long as the plan (nslices * taps * CinP * CoutB floats each, ~70 MB for a U-TAE
+            # step): buffers of an older plan (re-allocated gradient tensors) are dropped here
+            live = {j[1] for j in jobs}
+            for name in [k for k, b in self.bufs.items() if k.startswith("wgrad_slabs:") and b.data_ptr() not in live]:
+                del self.bufs[name]
         check(L_.c2s_wgrad_reduce_batch(plan["table"].data_ptr(), plan["njobs"], plan["blocks"], _stream()), "wgrad_reduce_batch")
 
     def sync_area(self, nbytes: int) -> Tensor:

@@ -36,14 +36,17 @@ class SeriesCollator:
 
     def __init__(self, channels_order: Optional[Sequence[int]] = None, mean=None, std=None, pad_value: float = 0.0,
                  device="cuda", max_size: Optional[int] = None, mode: str = "zero_copy", slots: int = 2,
-                 add_ndvi: bool = False, ndvi_bands: Optional[Tuple[int, int]] = None):
+                 add_ndvi: bool = False, ndvi_bands: Optional[Tuple[int, int]] = None,
+                 channels_like_pastis: Optional[bool] = None):
         """add_ndvi: append the dataset's NDVI channel (s2_ts_cz_crop.py:376-391,401-402): (NIR - red) / (NIR + red) of the RAW
         bands, 0 where the sum is 0 or the quotient leaves [-1, 1]; not normalised; the model then takes input_dim + 1 channels
-        (train.py:315-316).  ndvi_bands = (NIR, red) as positions in the RE-ORDERED channel list, default (6, 2) with a
-        PASTIS-like order and (3, 0) otherwise, as in the reference."""
+        (train.py:315-316).  ndvi_bands = (NIR, red) as positions in the RE-ORDERED channel list; default (6, 2) with
+        channels_like_pastis and (3, 0) without, as in the reference (s2_ts_cz_crop.py:384-389).  channels_like_pastis: None =
+        True exactly when channels_order is the reference's PASTIS order (a custom order never silently gets bands (6, 2))."""
         assert mode in ("zero_copy", "staged")
         self.add_ndvi, self.ndvi_bands = bool(add_ndvi), ndvi_bands
         self.order = list(channels_order) if channels_order is not None else None
+        self.channels_like_pastis = (self.order == CHANNELS_LIKE_PASTIS) if channels_like_pastis is None else bool(channels_like_pastis)
         self.mean = None if mean is None else np.ascontiguousarray(np.asarray(mean, dtype=np.float32))
         self.std = None if std is None else np.ascontiguousarray(np.asarray(std, dtype=np.float32))
         assert (self.mean is None) == (self.std is None), "mean and std come together"
@@ -77,7 +80,8 @@ class SeriesCollator:
         order = self.order if self.order is not None else list(range(Cs))
         ndvi_a = ndvi_b = -1
         if self.add_ndvi:
-            na, nb = self.ndvi_bands if self.ndvi_bands is not None else ((6, 2) if self.order is not None else (3, 0))
+            # the reference keys the default bands on channels_like_pastis, not on whether an order is given (s2_ts_cz_crop.py:384-389)
+            na, nb = self.ndvi_bands if self.ndvi_bands is not None else ((6, 2) if self.channels_like_pastis else (3, 0))
             ndvi_a, ndvi_b = order[na], order[nb]              # positions in the re-ordered list -> source channels
         Cc = len(order) + (1 if self.add_ndvi else 0)
         frame = Cs * H * W
@@ -144,13 +148,27 @@ class PrefetchLoader:
         self._dev = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
         self._stream = torch.cuda.Stream(device=self._dev)
         self._err: Optional[BaseException] = None
+        self._stop = threading.Event()
+        self._queue_mod = queue
         self._thread = threading.Thread(target=self._work, args=(iter(batches),), daemon=True)
         self._thread.start()
+
+    def _put(self, item) -> bool:
+        """Queue `item` unless the consumer went away (close()): never blocks forever on a full queue."""
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except self._queue_mod.Full:
+                continue
+        return False
 
     def _work(self, it) -> None:
         try:
             torch.cuda.set_device(self._dev)
             for series, dates, target in it:
+                if self._stop.is_set():
+                    break
                 with torch.cuda.stream(self._stream):
                     x, dd, valid = self.coll(series, dates)
                     y = None
@@ -158,16 +176,38 @@ class PrefetchLoader:
                         y = torch.as_tensor(np.asarray(target)).pin_memory().to(self.coll.device, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._stream)
-                self._q.put((x, dd, valid, y, ev))
+                if not self._put((x, dd, valid, y, ev)):
+                    break
         except BaseException as e:      # surfaced on the consumer side
             self._err = e
         finally:
-            self._q.put(None)
+            self._put(None)
+
+    def close(self) -> None:
+        """Stop the worker (a consumer that leaves the loop early calls this, or lets the object die): the worker gives up
+        its queue slot, finishes the copy it is in and exits; its pinned buffers and copy stream go with the collator."""
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except self._queue_mod.Empty:
+            pass
+        if self._thread.is_alive():
+            self._thread.join(timeout=5.0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __iter__(self):
         return self
 
     def __next__(self):
+        if self._err is not None and self._q.empty():
+            self._thread.join()
+            raise self._err
         item = self._q.get()
         if item is None:
             self._thread.join()

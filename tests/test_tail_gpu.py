@@ -230,6 +230,30 @@ def test_prefetch_loader_yields_the_same_batches():
         next(loader)
 
 
+def test_prefetch_loader_can_be_abandoned_and_surfaces_worker_errors():
+    """A consumer that leaves the loop early must not strand the worker on a full queue (close() / __del__), and an exception
+    in the worker (a bad batch) reaches the consumer at its next request, not after the queue has drained."""
+    from crop2seg_amd.utils import CHANNELS_LIKE_PASTIS, PrefetchLoader, SeriesCollator
+    rng = np.random.default_rng(3)
+
+    def gen(n, bad_at=None):
+        for k in range(n):
+            if k == bad_at:
+                raise ValueError("bad batch")
+            series = [rng.integers(0, 12000, (4, 10, 32, 32)).astype(np.uint16) for _ in range(2)]
+            dates = [np.arange(1, 5, dtype=np.int64) for _ in range(2)]
+            yield series, dates, None
+
+    loader = PrefetchLoader(gen(50), SeriesCollator(CHANNELS_LIKE_PASTIS))
+    next(loader)
+    loader.close()
+    assert not loader._thread.is_alive(), "the worker must exit once the consumer has gone away"
+    loader = PrefetchLoader(gen(5, bad_at=1), SeriesCollator(CHANNELS_LIKE_PASTIS))
+    next(loader)
+    with pytest.raises(ValueError, match="bad batch"):
+        next(loader)
+
+
 def test_predict_tile_timeunet_equals_patch_by_patch():
     """N3 on the model the web app runs (prediction.py:194-202 forces model='timeunet', B=1, T ~ 60): a 2x2 tile of
     128x128 patches with T=60 -- at B=1 the full-resolution L-TAE has exactly 4 register tiles per CU, the dispatch
