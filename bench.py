@@ -252,7 +252,9 @@ def main():
             lms = [a.elapsed_time(b) for a, b in lt]
             lavg = sum(lms) / len(lms)
             Ppix = B * H * H
-            lbytes = 4.0 * (Ppix * T * 64 + Ppix * 256 + 2 * 16 * Ppix * T)     # x read; emb, attn, attn_pre written
+            # x read; emb and attn_pre written, + the keep flags of the dropout as bits (the train step never reads the post-dropout
+            # weights of TimeUNet: they are not stored, engine.ltae_attention(need_attn=False))
+            lbytes = 4.0 * (Ppix * T * 64 + Ppix * 256 + 16 * Ppix * T) + 8.0 * 16 * Ppix
             ltae_roofline = {"bound": "hbm", "achieved": lbytes / (lavg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": lbytes / (lavg * 1e-3) / 8e12, "traffic": None,
                              "kernel": ltae_kernel_name(B, T, H), "avg_launch_ms": lavg,

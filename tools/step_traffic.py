@@ -34,9 +34,9 @@ def totals(d, counter):
     return acc
 
 
-def main(df, dw, out):
+def main(df, dw, out, steps=None):
     fe, wr = totals(df, "FETCH_SIZE"), totals(dw, "WRITE_SIZE")
-    steps = fe.get("adam_kernel", [0, 1])[1]
+    steps = int(steps) if steps else fe.get("adam_kernel", [0, 1])[1]       # (a trace without optimiser steps: pass the repeat count)
     rows = []
     for k in sorted(set(fe) | set(wr)):
         f, n = fe.get(k, [0.0, 0])
@@ -57,6 +57,6 @@ def main(df, dw, out):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) != 4:
+    if len(sys.argv) not in (4, 5):
         raise SystemExit(__doc__)
     main(*sys.argv[1:])
