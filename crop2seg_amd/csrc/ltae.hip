@@ -1763,6 +1763,10 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// H32: every dropout counter (row * ceil(T/2) + pair) fits in 32 bits (host check): the hash then needs no 64-bit index arithmetic
+// and no multiply of the (zero) high word -- the same bits as the general form (196 quarter-rate integer instructions per wave
+// were 11 % of this kernel's issue time).
+template <bool H32>
 __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
     extern __shared__ float lds[];
     float* adL = lds + R_AD;
@@ -1958,17 +1962,26 @@ __global__ __launch_bounds__(512) void ltae_reg_fwd_kernel(LtaeParams p) {
         const bool rng = p.drop_p > 0.f && p.keep == nullptr;
         DropCtx dc = {};
         if (rng) dc = drop_ctx(p);
+        // H32: counter of (head 4q + r, pixel, pair u) = ((4q) Ptot + pidx) half_t + t0 / 2  +  r (Ptot half_t)  +  u
+        const uint32_t k32 = (uint32_t)Ptot * (uint32_t)dc.half_t;
+        const uint32_t rb32 = ((uint32_t)(4 * q) * (uint32_t)Ptot + (uint32_t)pidx) * (uint32_t)dc.half_t + (uint32_t)(t0 >> 1);
         // head by head (4 hashes live at a time): t0 is even, so steps (2u, 2u+1) of a row share one hash
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int h = 4 * q + r;
             uint32_t bits[4] = {0u, 0u, 0u, 0u};
             if (rng) {
-                const uint64_t rb = (uint64_t)((long)h * Ptot + pidx) * (uint64_t)dc.half_t + (uint64_t)(t0 >> 1);
+                if constexpr (H32) {
+                    const uint32_t rb = rb32 + (uint32_t)r * k32;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t i2 = rb + (uint64_t)u;
-                    bits[u] = c2s_hash32((uint32_t)i2 ^ dc.key ^ (uint32_t)(i2 >> 32) * 0x85EBCA6Bu);
+                    for (int u = 0; u < 4; ++u) bits[u] = c2s_hash32((rb + (uint32_t)u) ^ dc.key);
+                } else {
+                    const uint64_t rb = (uint64_t)((long)h * Ptot + pidx) * (uint64_t)dc.half_t + (uint64_t)(t0 >> 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint64_t i2 = rb + (uint64_t)u;
+                        bits[u] = c2s_hash32((uint32_t)i2 ^ dc.key ^ (uint32_t)(i2 >> 32) * 0x85EBCA6Bu);
+                    }
                 }
             }
             float as = 0.f;
@@ -3356,7 +3369,8 @@ void init_hook() {
     C2S_RAISE_LDS(ltae_stream_bwd_gx64_kernel);
     C2S_RAISE_LDS(ltae_reg_bwd_heads_kernel<false>);
     C2S_RAISE_LDS(ltae_reg_bwd_heads_kernel<true>);
-    C2S_RAISE_LDS(ltae_reg_fwd_kernel);
+    C2S_RAISE_LDS(ltae_reg_fwd_kernel<false>);
+    C2S_RAISE_LDS(ltae_reg_fwd_kernel<true>);
 }
 C2sInitRegistrar registrar(init_hook);
 
@@ -3432,7 +3446,9 @@ extern "C" int c2s_ltae_attn_fwd_ws(const c2s_ltae_desc* d, const float* x, cons
     p.attn = attn; p.attn_pre = attn_pre; p.emb = emb; p.stats = stats;
     hipStream_t st = (hipStream_t)stream;
     if (use_reg_fwd(d)) {
-        hipLaunchKernelGGL(ltae_reg_fwd_kernel, dim3(d->B * (d->HW / RPX)), dim3(512), R_FLOATS * sizeof(float), st, p);
+        const bool h32 = (unsigned long long)NH * d->B * d->HW * ((d->T + 1) / 2) <= 0xFFFFFFFFull;
+        if (h32) hipLaunchKernelGGL(ltae_reg_fwd_kernel<true>, dim3(d->B * (d->HW / RPX)), dim3(512), R_FLOATS * sizeof(float), st, p);
+        else hipLaunchKernelGGL(ltae_reg_fwd_kernel<false>, dim3(d->B * (d->HW / RPX)), dim3(512), R_FLOATS * sizeof(float), st, p);
         C2S_CHECK_LAUNCH("ltae_reg_fwd");
         return C2S_OK;
     }

@@ -15,7 +15,7 @@ void c2s_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int c2s_abi_version(void) { return 3; }
+extern "C" int c2s_abi_version(void) { return 4; }
 extern "C" const char* c2s_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- per-device one-time set-up

@@ -252,13 +252,15 @@ class TrainStep:
             self.check_health()                             # never bake a poisoned sync area into a graph
             scale = 1.0 / self.dp.world if self.dp is not None else 1.0
             self.graph_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_fb):
+            # capture_error_mode thread_local: the process group's watchdog thread keeps polling the events of earlier collectives
+            # (hipEventQuery), which the default global mode forbids while ANY thread captures
+            with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
                 self.seed_dev.add_(1)
                 self.static_loss, self.static_logits = self._forward_backward(self.static_x, self.static_dates, self.static_y, drop)
         finally:
             E.REDUCE_BATCH = batch0
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt):
+        with torch.cuda.graph(self.graph_opt, capture_error_mode="thread_local"):
             self.step_dev.add_(1)
             E.adam_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, 0, self.lr, self.betas[0],
                         self.betas[1], self.eps, grad_scale=scale, step_dev=self.step_dev)

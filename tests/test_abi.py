@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/c2s_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes binding and header disagree"
-    assert _lib.lib().c2s_abi_version() == 3
+    assert _lib.lib().c2s_abi_version() == 4
 
 
 def test_argument_validation_without_gpu():
