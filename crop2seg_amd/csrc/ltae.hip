@@ -3137,8 +3137,9 @@ __global__ __launch_bounds__(512) void ltae_reg_bwd_heads_kernel(LtaeParams p, S
 // limit of a 1024-thread workgroup (25 scratch reloads in its inner loops).  Here a wave owns ONE group, so U[h][4g..4g+3] is
 // wave-uniform (SGPR operands), only r[16][4] lives in VGPRs, rows are 256 bytes, and the attention / dscore rows of 16 time
 // steps are staged at once (128 KB, the area r passed through): two barriers per 16 steps instead of per 4.
-constexpr int GXT = 16;                            // time steps per staged chunk
-constexpr int GX_FLOATS = 2 * GXT * 4 * 64 * 4;    // [arr 2][GXT][h/4][64 px][4] = 32,768 floats = 128 KB
+constexpr int GXT = 8;                             // time steps per staged chunk
+constexpr int GX_BUF = 2 * GXT * 16 * 64;          // one chunk: [arr 2][GXT][16 h][64 px] = 16,384 floats
+constexpr int GX_FLOATS = 2 * GX_BUF;              // two chunks in flight = 128 KB
 
 __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p, StreamBwd sb) {
     constexpr int C = 64, CPG = 4;
@@ -3221,65 +3222,63 @@ __global__ __launch_bounds__(1024) void ltae_stream_bwd_gx64_kernel(LtaeParams p
     const size_t hstride = (size_t)p.B * T * HW;
     float dgam[CPG] = {0.f, 0.f, 0.f, 0.f}, dbet[CPG] = {0.f, 0.f, 0.f, 0.f};     // sum_t d xhat * xn, sum_t d xhat (this pixel)
 
-    for (int tc0 = 0; tc0 < T; tc0 += GXT) {
-        __syncthreads();                           // r (first pass) or the previous chunk consumed
-        // stage attn and gs of GXT steps: 2 x GXT x 16 rows of 64 pixels, 32 rows per wave, 8 at a time
+    // attn / gs rows of GXT steps per chunk by LDS-DMA, two buffers: wave w fetches step (w & 7) of array (w >> 3), 4 heads x 64
+    // pixels per instruction; chunk k + 1 is in flight while chunk k is consumed
+    const float* asrc = rekeep ? p.attn_pre_in : p.attn_in;
+    auto issue_dma = [&](int tc0, int kbuf) {
+        const int tt = w & 7, t = tc0 + tt < T ? tc0 + tt : T - 1;
+        const float* src = (w >> 3) == 0 ? asrc : p.GS;
 #pragma unroll
-        for (int part = 0; part < 4; ++part) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = w * 32 + part * 8 + i;                  // 0 .. 511
-                const int arr = row >> 8, tt = (row >> 4) & 15, h = row & 15;
-                const int t = tc0 + tt < T ? tc0 + tt : T - 1;
-                const size_t o = (size_t)h * hstride + ((size_t)b * T + t) * HW + pix;
-                // (a chunk of 16 steps lies in one 32-bit half of the keep word: 32-bit shifts only)
-                v[i] = arr == 0 ? (rekeep ? p.attn_pre_in[o] * (((kb32[(h * 64 + lane) * 2 + (tc0 >> 5)] >> (t & 31)) & 1u) ? kscale : 0.f) : p.attn_in[o])
-                                : p.GS[o];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = w * 32 + part * 8 + i;
-                const int arr = row >> 8, tt = (row >> 4) & 15, h = row & 15;
-                lds[(((arr * GXT + tt) * 4 + (h >> 2)) * 64 + lane) * 4 + (h & 3)] = v[i];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int h = 4 * j + (lane >> 4);
+            const size_t o = (size_t)h * hstride + ((size_t)b * T + t) * HW + (pix - lane) + (lane & 15) * 4;
+            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(src + o), (C2S_AS3 void*)(lds + kbuf * GX_BUF + (w * 16 + j * 4) * 64), 16, 0, 0);
         }
-        __syncthreads();
+    };
+    float xn[2][CPG];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = t0 + u < T ? t0 + u : T - 1;
+#pragma unroll
+            for (int cc = 0; cc < CPG; ++cc) xn[u][cc] = xg[(size_t)(t * C + cc) * HW];
+        }
+    };
+    __syncthreads();                               // r read by every wave: the area becomes the two chunk buffers
+    issue_dma(0, 0);
+    issue(0);
+    for (int tc0 = 0, kb = 0; tc0 < T; tc0 += GXT, kb ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // chunk kb landed (every wave's part); chunk kb ^ 1 consumed
+        if (tc0 + GXT < T) issue_dma(tc0 + GXT, kb ^ 1);
+        float* bufk = lds + kb * GX_BUF;
+        if (rekeep) {                              // thread (head w, pixel lane): the 8 steps of the chunk lie in one byte of the keep word
+            const unsigned kbyte = kb32[(w * 64 + lane) * 2 + (tc0 >> 5)] >> (tc0 & 31);
+#pragma unroll
+            for (int tt = 0; tt < GXT; ++tt) bufk[(tt * NH + w) * 64 + lane] *= ((kbyte >> tt) & 1u) ? kscale : 0.f;
+            lds_barrier();
+        }
         const int tn = T - tc0 < GXT ? T - tc0 : GXT;
-        float xn[2][CPG];
-        auto issue = [&](int tt0) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = tc0 + tt0 + u < T ? tc0 + tt0 + u : T - 1;
-#pragma unroll
-                for (int cc = 0; cc < CPG; ++cc) xn[u][cc] = xg[(size_t)(t * C + cc) * HW];
-            }
-        };
-        issue(0);
         for (int tt0 = 0; tt0 < tn; tt0 += 2) {
             float xv[2][CPG];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int cc = 0; cc < CPG; ++cc) xv[u][cc] = xn[u][cc];
-            if (tt0 + 2 < tn) issue(tt0 + 2);
+            if (tc0 + tt0 + 2 < T) issue(tc0 + tt0 + 2);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int tt = tt0 + u, t = tc0 + tt;
                 if (tt < tn) {
                     float acc[CPG] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int hq = 0; hq < 4; ++hq) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(lds + (((0 * GXT + tt) * 4 + hq) * 64 + lane) * 4);
-                        const f32x4 gs = *reinterpret_cast<const f32x4*>(lds + (((1 * GXT + tt) * 4 + hq) * 64 + lane) * 4);
+                    for (int h = 0; h < NH; ++h) {
+                        const float a = bufk[(tt * NH + h) * 64 + lane];
+                        const float gs = bufk[((GXT + tt) * NH + h) * 64 + lane];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int h = hq * 4 + kk;
-#pragma unroll
-                            for (int cc = 0; cc < CPG; ++cc) {
-                                acc[cc] = fmaf(a[kk], r[h][cc], acc[cc]);
-                                acc[cc] = fmaf(gs[kk], ug[h][cc], acc[cc]);
-                            }
+                        for (int cc = 0; cc < CPG; ++cc) {
+                            acc[cc] = fmaf(a, r[h][cc], acc[cc]);
+                            acc[cc] = fmaf(gs, ug[h][cc], acc[cc]);
                         }
                     }
 #pragma unroll
