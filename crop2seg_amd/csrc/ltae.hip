@@ -1085,29 +1085,59 @@ __global__ __launch_bounds__(256) void ltae_lds_bwd_kernel(LtaeParams p, StreamB
 }
 
 // ------------------------------------------------------------------------------------------ reductions
-// out[grp][k] = sum_{i<count} part[(grp*count + i)*K + k]; one wave per output element, lanes stride the tiles
-// (fixed lane assignment + fixed shuffle tree: bitwise reproducible)
-__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int count,
-                                                             int K, long total) {
-    const long e = blockIdx.x;
-    if (e >= total) return;
-    const long grp = e / K;
-    const int k = (int)(e % K);
+// out[grp][k] = sum_{i<count} part[(grp*count + i)*K + k] with lane = k: a wave reads 256-byte pieces of the rows (rounds 1-3: one
+// wave per output element, one float per row and lane -- 19x the partials' bytes fetched at the TimeUNet shape: 0.61 GB, 0.22 ms
+// in three launches).  The 16 waves of a workgroup take
+// the rows i = w, w + 16, ... with 16 requests in flight each and are added in wave order through LDS; more than 512 rows go
+// through RR_SLICES double partials per group first.  Fixed order: bitwise reproducible.
+constexpr int RR_SLICES = 32;
+template <typename TI, typename TO>
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const TI* __restrict__ part, TO* __restrict__ out, TO* __restrict__ out1,
+                                                           int count, int K, int slices, int rows_per_slice) {
+    __shared__ double sh[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const int grp = blockIdx.y / slices, sl = blockIdx.y - grp * slices;
+    const int r0 = sl * rows_per_slice;
+    const int n = count - r0 < rows_per_slice ? count - r0 : rows_per_slice;
+    const bool live = k < K;
+    const TI* src = part + ((size_t)grp * count + r0) * K + (live ? k : 0);
     double s = 0.0;
-    for (int i = threadIdx.x; i < count; i += 64) s += part[((size_t)grp * count + i) * K + k];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) out[e] = (float)s;
+    for (int i0 = w; i0 < n; i0 += 256) {
+        TI v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + 16 * u;
+            v[u] = (live && i < n) ? src[(size_t)i * K] : TI(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && live) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) t += sh[ww][lane];
+        if (out1 != nullptr) ((k & 1) ? out1 : out)[k >> 1] = (TO)t;      // interleaved pairs to two arrays (one group)
+        else out[(size_t)blockIdx.y * K + k] = (TO)t;
+    }
 }
 
-// the same sum for interleaved (d gamma, d beta) partials [count][C][2], written to two arrays (was: a [C][2] scratch and two
-// strided hipMemcpy2DAsync)
-__global__ __launch_bounds__(64) void reduce_partials_split2_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                                                    float* __restrict__ out1, int count, int C) {
-    const int e = blockIdx.x, K = 2 * C;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < count; i += 64) s += part[(size_t)i * K + e];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) ((e & 1) ? out1 : out0)[e >> 1] = (float)s;
+// out[grp][k] = sum_{i < count} part[(grp * count + i) * K + k]; tmp: groups * RR_SLICES * K doubles when count > 512
+void reduce_rows(const float* part, float* out, int groups, int count, int K, double* tmp, hipStream_t st, float* out1 = nullptr) {
+    const int kb = (K + 63) / 64;
+    if (count <= 512 || tmp == nullptr) {
+        hipLaunchKernelGGL((reduce_rows_kernel<float, float>), dim3(kb, groups), dim3(1024), 0, st, part, out, out1, count, K, 1, count);
+    } else {
+        const int rps_min = (count + RR_SLICES - 1) / RR_SLICES;
+        const int rps = rps_min > 256 ? rps_min : 256;          // 16 rows per wave and batch of requests
+        const int slices = (count + rps - 1) / rps;
+        hipLaunchKernelGGL((reduce_rows_kernel<float, double>), dim3(kb, groups * slices), dim3(1024), 0, st, part, tmp, (double*)nullptr,
+                           count, K, slices, rps);
+        hipLaunchKernelGGL((reduce_rows_kernel<double, float>), dim3(kb, groups), dim3(1024), 0, st, (const double*)tmp, out, out1,
+                           slices, K, 1, slices);
+    }
 }
 
 // gU[h,c] = sum_{b,pix} V[b,h,c,pix]     one wave per (h,c)
@@ -3484,12 +3514,16 @@ extern "C" int c2s_ltae_attn_fwd(const c2s_ltae_desc* d, const float* x, const f
 }
 
 // workspace: GS [16,B,T,HW] | V [B,16,C,HW] | Z [B,16,C,HW] | part_s0 [tiles][T][16] | part_bc [tiles][256]
-//            | part_gb [tiles][C][2]
+//            | part_gb [tiles][C][2] | the slice sums of reduce_rows (doubles)
+static size_t reduce_tmp_floats(const c2s_ltae_desc* d) {      // groups * RR_SLICES * K doubles for the widest of the three sums
+    const size_t kmax = (size_t)d->B * d->T * NH > (size_t)NH * d->C ? (size_t)d->B * d->T * NH : (size_t)NH * d->C;
+    return 2 * (size_t)RR_SLICES * (kmax > 256 ? kmax : 256);
+}
 extern "C" size_t c2s_ltae_bwd_workspace_floats(const c2s_ltae_desc* d) {
     if (!d) return 0;
     const size_t tiles = (size_t)d->B * ((d->HW + 3) / 4);   // upper bound (4-pixel tiles)
     return (size_t)NH * d->B * d->T * d->HW + 2 * (size_t)d->B * NH * d->C * d->HW + tiles * d->T * NH + tiles * 256 +
-           tiles * d->C * 2;
+           tiles * d->C * 2 + 2 + reduce_tmp_floats(d);
 }
 
 extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const float* gamma, const float* beta,
@@ -3522,6 +3556,8 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     p.part_s0 = p.Z + (size_t)d->B * NH * d->C * d->HW;
     p.part_bc = p.part_s0 + tiles_ws * d->T * NH;
     p.part_gb = p.part_bc + tiles_ws * 256;
+    float* rt_ = p.part_gb + tiles_ws * d->C * 2;
+    double* rtmp = reinterpret_cast<double*>(rt_ + (((uintptr_t)rt_ >> 2) & 1));      // 8-byte aligned
     hipStream_t st = (hipStream_t)stream;
     c2s_ensure_init();
     StreamBwd sb = {};
@@ -3562,21 +3598,18 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
     // reductions
     const int tpb = (d->HW + PT - 1) / PT;
     {   // gs0[b][t][h] = sum over the tiles of b
-        const long total = (long)d->B * d->T * NH;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(total), dim3(64), 0, st, p.part_s0, gs0, tpb,
-                           d->T * NH, total);
+        reduce_rows(p.part_s0, gs0, d->B, tpb, d->T * NH, rtmp, st);
         C2S_CHECK_LAUNCH("ltae_reduce_s0");
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(256), dim3(64), 0, st, p.part_bc, gbc, (int)tiles, 256, (long)256);
+    reduce_rows(p.part_bc, gbc, 1, (int)tiles, 256, rtmp, st);
     C2S_CHECK_LAUNCH("ltae_reduce_bc");
     {   // interleaved (dgamma, dbeta) partials -> the two outputs
         const int gb_tiles = reg_heads ? d->B * (d->HW / 64) : (int)tiles;
-        hipLaunchKernelGGL(reduce_partials_split2_kernel, dim3(2 * d->C), dim3(64), 0, st, p.part_gb, ggamma, gbeta, gb_tiles, d->C);
+        reduce_rows(p.part_gb, ggamma, 1, gb_tiles, 2 * d->C, rtmp, st, gbeta);
         C2S_CHECK_LAUNCH("ltae_reduce_gb");
     }
     if (stream_path || lds_path) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(NH * d->C), dim3(64), 0, st, sb.part_U, gU, (int)tiles, NH * d->C,
-                           (long)NH * d->C);
+        reduce_rows(sb.part_U, gU, 1, (int)tiles, NH * d->C, rtmp, st);
     } else {
         hipLaunchKernelGGL(sum_over_pixels_kernel, dim3(NH * d->C), dim3(64), 0, st, p.V, gU, d->B, NH * d->C, d->HW);
     }
@@ -3589,8 +3622,7 @@ extern "C" int c2s_ltae_attn_bwd(const c2s_ltae_desc* d, const float* x, const f
         float* part_wc = sb.part_U + tiles * NH * d->C;
         hipLaunchKernelGGL(gwc_mfma_kernel, dim3(NH, slices), dim3(256), 0, st, g_emb, p.Z, part_wc, d->B, d->HW, tps);
         C2S_CHECK_LAUNCH("ltae_gWc_mfma");
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(NH * DV * d->C), dim3(64), 0, st, part_wc, gWc, slices, NH * DV * d->C,
-                           (long)NH * DV * d->C);
+        reduce_rows(part_wc, gWc, 1, slices, NH * DV * d->C, nullptr, st);
         C2S_CHECK_LAUNCH("ltae_gWc_reduce");
     } else if (g_emb != nullptr) {
         hipLaunchKernelGGL(gwc_kernel, dim3(NH * d->C), dim3(256), 0, st, g_emb, p.Z, gWc, d->B, d->C, d->HW);
@@ -3667,7 +3699,7 @@ extern "C" int c2s_pixel_gn_bwd(const float* x, const float* gy, const float* ga
     hipLaunchKernelGGL(pixel_gn_bwd_kernel, dim3(B * groups * chunks), dim3(64), 0, st, x, gy, gamma, stats, gx, workspace,
                        B, C, HW, groups, chunks);
     C2S_CHECK_LAUNCH("pixel_gn_bwd");
-    hipLaunchKernelGGL(reduce_partials_split2_kernel, dim3(2 * C), dim3(64), 0, st, workspace, dgamma, dbeta, B * chunks, C);
+    reduce_rows(workspace, dgamma, 1, B * chunks, 2 * C, nullptr, st, dbeta);
     C2S_CHECK_LAUNCH("pixel_gn_reduce");
     return C2S_OK;
 }
