@@ -498,6 +498,8 @@ def _ltae_state(C, g, flavour="tame"):
     (2, 9, 64, 128, True, True, True),
     (2, 1, 64, 128, True, False, True),
     (4, 7, 64, 64, True, True, True),       # 64x64 planes: 256 tiles per batch element, exactly 4 tiles per CU
+    # 112x112 planes: 2352 tiles of 16 pixels / 588 of 64 -- the partial sums go through ragged slices (9 x 256 + 48, 2 x 256 + 76)
+    (3, 5, 64, 112, True, True, True),
 ])
 def test_ltae_attention_fwd_bwd(B, T, C, h, with_emb, pad, drop):
     E, L = _engine()
