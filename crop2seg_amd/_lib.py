@@ -146,8 +146,10 @@ SIGNATURES = {
     "c2s_region_relabel": (I, [P, P, I, I, I, I, C.c_longlong, P]),
     "c2s_focal_ce_workspace_floats": (SZ, []),
     "c2s_focal_ce": (I, [P, P, P, P, I, I, I, F, C.c_longlong, I, P, SZ, P]),
+    "c2s_focal_ce_ex": (I, [P, P, P, P, P, I, I, I, F, C.c_longlong, I, I, P, SZ, P]),
     "c2s_smooth_ce_workspace_floats": (SZ, []),
     "c2s_smooth_ce": (I, [P, P, P, P, P, P, I, I, I, I, F, C.c_longlong, I, P, SZ, P]),
+    "c2s_smooth_ce_ex": (I, [P, P, P, P, P, P, P, I, I, I, I, F, C.c_longlong, I, I, P, SZ, P]),
     "c2s_collate_series": (I, [P, I, P, P, P, P, P, I, I, I, I, I, C.POINTER(I), C.POINTER(F), C.POINTER(F), F, P]),
     "c2s_collate_series_ndvi": (I, [P, I, P, P, P, P, P, I, I, I, I, I, C.POINTER(I), C.POINTER(F), C.POINTER(F), F, I, I, P]),
     "c2s_softmax_stitch": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),

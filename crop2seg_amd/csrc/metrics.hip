@@ -117,13 +117,18 @@ __global__ __launch_bounds__(256) void region_relabel_kernel(const int64_t* __re
     }
 }
 
-// FocalCELoss (size_average=True, weight=None): part[block] = (sum over kept pixels of -(1-pt)^g log pt, #kept)
+// FocalCELoss (focal_loss.py:12-45): part[block] = (sum over kept pixels of f = -(1-pt)^g log pt, #kept, sum of w[target]).
+// With class weights the reference multiplies a [N,1] column of weights by the [N] row of focal terms (focal_loss.py:36-39:
+// `w.gather(1, target)` keeps the column shape) -- an N x N outer product, so its value is
+//   size_average: mean_i(w_i) * mean_j(f_j),   else: sum_i(w_i) * sum_j(f_j)
+// and that is what is computed here (without the N^2 tensor, which is 17 GB at B=4, 128x128); pinned by fixtures written from
+// the imported module (oracle/make_golden_tail.py).  d/dz: the weights do not depend on the logits -- a constant factor.
 __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                        float* __restrict__ part, int B, int K, int HW, float gamma,
-                                                        long long ignore_index) {
-    __shared__ float red[4][2];
+                                                        const float* __restrict__ class_w, float* __restrict__ part, int B, int K,
+                                                        int HW, float gamma, long long ignore_index) {
+    __shared__ float red[4][3];
     const long total = (long)B * HW;
-    float num = 0.f, cnt = 0.f;
+    float num = 0.f, cnt = 0.f, wsum = 0.f;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long long t = target[e];
         if (t == ignore_index || t < 0 || t >= K) continue;
@@ -137,23 +142,26 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict_
         const float pt = expf(logpt);
         num += -powf(1.f - pt, gamma) * logpt;
         cnt += 1.f;
+        wsum += class_w ? class_w[t] : 1.f;
     }
-    num = wave_sum(num); cnt = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = cnt; }
+    num = wave_sum(num); cnt = wave_sum(cnt); wsum = wave_sum(wsum);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = cnt; red[threadIdx.x >> 6][2] = wsum; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[blockIdx.x * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        part[blockIdx.x * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) part[blockIdx.x * 3 + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
     }
 }
 
+// tot = (sum f, #kept, d loss / d (sum f))
 __global__ void focal_finalize_kernel(const float* __restrict__ part, float* __restrict__ tot, float* __restrict__ loss,
-                                      int blocks, int accumulate) {
+                                      int blocks, int weighted, int size_average, int accumulate) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double num = 0, cnt = 0;
-    for (int i = 0; i < blocks; ++i) { num += part[i * 2]; cnt += part[i * 2 + 1]; }
-    tot[0] = (float)num; tot[1] = (float)cnt;
-    const float l = (float)(num / cnt);
+    double num = 0, cnt = 0, wsum = 0;
+    for (int i = 0; i < blocks; ++i) { num += part[i * 3]; cnt += part[i * 3 + 1]; wsum += part[i * 3 + 2]; }
+    const double scale = weighted ? (size_average ? wsum / (cnt * cnt) : wsum) : (size_average ? 1.0 / cnt : 1.0);
+    tot[0] = (float)num; tot[1] = (float)cnt; tot[2] = (float)scale;
+    const float l = (float)(num * scale);
     *loss = accumulate ? *loss + l : l;
 }
 
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ tot, float* __restrict__ glogits, int B,
                                                         int K, int HW, float gamma, long long ignore_index) {
     const long total = (long)B * HW;
-    const float inv_n = 1.f / tot[1];
+    const float inv_n = tot[2];
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int pix = (int)(e % HW), b = (int)(e / HW);
         const float* lp = logits + (size_t)b * K * HW + pix;
@@ -198,13 +206,13 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
 // on those; here they are counted and the pixel contributes nothing).
 __global__ __launch_bounds__(256) void smooth_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                         const float* __restrict__ class_w, const float* __restrict__ bg,
-                                                        float* __restrict__ part, float* __restrict__ glogits, int B, int K,
-                                                        int H, int W, float ls, long long bg_index) {
+                                                        float* __restrict__ part, float* __restrict__ glogits,
+                                                        float* __restrict__ pixel_loss, int B, int K, int H, int W, float ls,
+                                                        long long bg_index, float inv_n) {
     __shared__ float red[4][2];
     const int HW = H * W;
     const long total = (long)B * HW;
     const float eps = ls / (float)K;
-    const float inv_n = 1.f / (float)total;
     float num = 0.f, bad = 0.f;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int pix = (int)(e % HW), b = (int)(e / HW);
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(256) void smooth_ce_kernel(const float* __restrict_
         if (t < 0 || t >= K) {
             bad += 1.f;
             if (gp) for (int k = 0; k < K; ++k) gp[(size_t)k * HW] = 0.f;
+            if (pixel_loss) pixel_loss[e] = 0.f;
             continue;
         }
         unsigned mask = 1u << (int)t;
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(256) void smooth_ce_kernel(const float* __restrict_
             wsum += wt;
         }
         num += loss;
+        if (pixel_loss) pixel_loss[e] = loss;
         if (gp) {
             for (int k = 0; k < K; ++k) {
                 const float tk = is_bg ? bg[k] : (((mask >> k) & 1u) ? exp_large : eps);
@@ -319,21 +329,22 @@ extern "C" int c2s_region_relabel(const long long* y, long long* y_out, int B, i
     return C2S_OK;
 }
 
-extern "C" size_t c2s_focal_ce_workspace_floats(void) { return 2 * FOCAL_BLOCKS + 2; }
+extern "C" size_t c2s_focal_ce_workspace_floats(void) { return 3 * FOCAL_BLOCKS + 4; }
 
-extern "C" int c2s_focal_ce(const float* logits, const long long* target, float* loss, float* glogits, int B, int K, int HW,
-                            float gamma, long long ignore_index, int accumulate_loss, float* workspace, size_t ws_floats,
-                            void* stream) {
+extern "C" int c2s_focal_ce_ex(const float* logits, const long long* target, const float* class_w, float* loss, float* glogits,
+                               int B, int K, int HW, float gamma, long long ignore_index, int size_average, int accumulate_loss,
+                               float* workspace, size_t ws_floats, void* stream) {
     C2S_REQUIRE(logits && target && loss && workspace, "focal_ce: null pointer");
     C2S_REQUIRE(B > 0 && K > 0 && HW > 0 && gamma >= 0.f, "focal_ce: bad args");
     C2S_REQUIRE(ws_floats >= c2s_focal_ce_workspace_floats(), "focal_ce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = grid_for((long)B * HW, FOCAL_BLOCKS);
-    float* tot = workspace + 2 * FOCAL_BLOCKS;
-    hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, (const int64_t*)target, workspace, B, K, HW,
-                       gamma, ignore_index);
+    float* tot = workspace + 3 * FOCAL_BLOCKS;
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, (const int64_t*)target, class_w, workspace, B, K,
+                       HW, gamma, ignore_index);
     C2S_CHECK_LAUNCH("focal_fwd");
-    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks, accumulate_loss);
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks, class_w != nullptr ? 1 : 0,
+                       size_average, accumulate_loss);
     C2S_CHECK_LAUNCH("focal_finalize");
     if (glogits) {
         hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, st, logits, (const int64_t*)target, tot,
@@ -343,23 +354,41 @@ extern "C" int c2s_focal_ce(const float* logits, const long long* target, float*
     return C2S_OK;
 }
 
+extern "C" int c2s_focal_ce(const float* logits, const long long* target, float* loss, float* glogits, int B, int K, int HW,
+                            float gamma, long long ignore_index, int accumulate_loss, float* workspace, size_t ws_floats,
+                            void* stream) {
+    return c2s_focal_ce_ex(logits, target, nullptr, loss, glogits, B, K, HW, gamma, ignore_index, 1, accumulate_loss, workspace,
+                           ws_floats, stream);
+}
+
 extern "C" size_t c2s_smooth_ce_workspace_floats(void) { return 2 * FOCAL_BLOCKS + 2; }
 
-extern "C" int c2s_smooth_ce(const float* logits, const long long* target, const float* class_w, const float* bg_distrib,
-                             float* loss, float* glogits, int B, int K, int H, int W, float label_smoothing,
-                             long long bg_index, int accumulate_loss, float* workspace, size_t ws_floats, void* stream) {
+// reduction: 0 'mean' (over all B*H*W pixels), 1 'sum', 2 'none' (pixel_loss [B,H,W] receives the per-pixel terms; *loss their
+// sum and glogits the gradient of that sum)
+extern "C" int c2s_smooth_ce_ex(const float* logits, const long long* target, const float* class_w, const float* bg_distrib,
+                                float* loss, float* glogits, float* pixel_loss, int B, int K, int H, int W, float label_smoothing,
+                                long long bg_index, int reduction, int accumulate_loss, float* workspace, size_t ws_floats,
+                                void* stream) {
     C2S_REQUIRE(logits && target && loss && workspace, "smooth_ce: null pointer");
     C2S_REQUIRE(B > 0 && H > 0 && W > 0 && K >= 1 && K <= MAXK, "smooth_ce: 1 <= K <= 32 classes");
     C2S_REQUIRE(label_smoothing >= 0.f && label_smoothing <= 1.f, "smooth_ce: label_smoothing outside [0, 1]");
+    C2S_REQUIRE(reduction >= 0 && reduction <= 2 && (reduction != 2 || pixel_loss != nullptr), "smooth_ce: reduction 0 mean / 1 sum / 2 none (needs pixel_loss)");
     C2S_REQUIRE(ws_floats >= c2s_smooth_ce_workspace_floats(), "smooth_ce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = grid_for((long)B * H * W, FOCAL_BLOCKS);
     float* tot = workspace + 2 * FOCAL_BLOCKS;
+    const double npix = reduction == 0 ? (double)B * H * W : 1.0;
     hipLaunchKernelGGL(smooth_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, (const int64_t*)target, class_w, bg_distrib,
-                       workspace, glogits, B, K, H, W, label_smoothing, bg_index);
+                       workspace, glogits, pixel_loss, B, K, H, W, label_smoothing, bg_index, (float)(1.0 / npix));
     C2S_CHECK_LAUNCH("smooth_ce");
-    hipLaunchKernelGGL(smooth_ce_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks, (double)B * H * W,
-                       accumulate_loss);
+    hipLaunchKernelGGL(smooth_ce_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, tot, loss, blocks, npix, accumulate_loss);
     C2S_CHECK_LAUNCH("smooth_ce_finalize");
     return C2S_OK;
+}
+
+extern "C" int c2s_smooth_ce(const float* logits, const long long* target, const float* class_w, const float* bg_distrib,
+                             float* loss, float* glogits, int B, int K, int H, int W, float label_smoothing,
+                             long long bg_index, int accumulate_loss, float* workspace, size_t ws_floats, void* stream) {
+    return c2s_smooth_ce_ex(logits, target, class_w, bg_distrib, loss, glogits, nullptr, B, K, H, W, label_smoothing, bg_index, 0,
+                            accumulate_loss, workspace, ws_floats, stream);
 }

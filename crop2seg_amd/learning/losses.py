@@ -30,9 +30,12 @@ def boundary_target(y: Tensor) -> Tensor:
 
 
 def focal_ce(logits: Tensor, target: Tensor, gamma: float = 1.0, ignore_index: int = -100, want_grad: bool = False,
-             ws: Optional[E.Workspace] = None, loss_out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-    """FocalCELoss(gamma, size_average=True, weight=None)(logits [B,K,H,W], target [B,H,W]) (focal_loss.py:19-44).
-    Returns (loss[1], dlogits | None).  With `loss_out` the value is ADDED to that tensor (utils.py:324)."""
+             ws: Optional[E.Workspace] = None, loss_out: Optional[Tensor] = None, class_w: Optional[Tensor] = None,
+             size_average: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """FocalCELoss(gamma, size_average, ignore_index, weight)(logits [B,K,H,W], target [B,H,W]) (focal_loss.py:12-45).
+    Returns (loss[1], dlogits | None).  With `loss_out` the value is ADDED to that tensor (utils.py:324).  With class weights the
+    value is the reference's: mean(w[target]) * mean(focal terms) (sums for size_average=False) -- its [N,1] x [N] broadcast, see
+    csrc/metrics.hip."""
     if not logits.is_cuda:
         raise RuntimeError("crop2seg_amd runs on MI355X only (no CPU fallback)")
     logits = logits.contiguous()
@@ -43,23 +46,37 @@ def focal_ce(logits: Tensor, target: Tensor, gamma: float = 1.0, ignore_index: i
     w = ws.get("focal", lib().c2s_focal_ce_workspace_floats())
     loss = loss_out if loss_out is not None else torch.empty(1, device=logits.device, dtype=torch.float32)
     gl = torch.empty_like(logits) if want_grad else None
-    check(lib().c2s_focal_ce(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), gl.data_ptr() if want_grad else None, B, K,
-                             HW, float(gamma), int(ignore_index), 1 if loss_out is not None else 0, w.data_ptr(), w.numel(),
-                             E._stream()), "focal_ce")
+    if class_w is not None:
+        class_w = class_w.detach().to(logits.device, torch.float32).contiguous()
+        if class_w.numel() != K:
+            raise ValueError(f"FocalCELoss: {class_w.numel()} class weights for {K} classes")
+    check(lib().c2s_focal_ce_ex(logits.data_ptr(), target.data_ptr(), E._ptr(class_w), loss.data_ptr(),
+                                gl.data_ptr() if want_grad else None, B, K, HW, float(gamma), int(ignore_index),
+                                1 if size_average else 0, 1 if loss_out is not None else 0, w.data_ptr(), w.numel(),
+                                E._stream()), "focal_ce")
     return loss, gl
 
 
 class FocalCELoss:
-    """Call-compatible with the reference's module for the configuration iterate() uses (gamma=2.0, no class weights,
-    mean reduction); the value carries no autograd graph -- see TrainStep(add_boundary_loss=True) for training."""
+    """Call-compatible with the reference's module (focal_loss.py:7-45: gamma, size_average, ignore_index, weight); the value
+    carries no autograd graph -- `grad()` returns dL/dlogits of the last call with want_grad=True, and
+    TrainStep(add_boundary_loss=True) is the training route."""
 
-    def __init__(self, gamma: float = 1.0, size_average: bool = True, ignore_index: int = -100, weight=None):
-        if weight is not None or not size_average:
-            raise NotImplementedError("FocalCELoss: class weights / sum reduction are not built")
-        self.gamma, self.ignore_index = gamma, ignore_index
+    def __init__(self, gamma: float = 1.0, size_average: bool = True, ignore_index: int = -100, weight: Optional[Tensor] = None):
+        self.gamma, self.size_average, self.ignore_index, self.weight = gamma, bool(size_average), ignore_index, weight
+        self._grad: Optional[Tensor] = None
 
-    def __call__(self, preds: Tensor, target: Tensor) -> Tensor:
-        return focal_ce(preds, target, self.gamma, self.ignore_index)[0][0]
+    def __call__(self, preds: Tensor, target: Tensor, want_grad: bool = False) -> Tensor:
+        if preds.dim() == 2:                        # (N, C) logits with (N,) targets
+            preds, target = preds.t().reshape(1, preds.shape[1], preds.shape[0], 1), target.reshape(1, -1, 1)
+        loss, self._grad = focal_ce(preds, target, self.gamma, self.ignore_index, want_grad, class_w=self.weight,
+                                    size_average=self.size_average)
+        return loss[0]
+
+    forward = __call__
+
+    def grad(self) -> Optional[Tensor]:
+        return self._grad
 
 
 DEFAULT_CLASS_PROPORTIONS = (0.3111, 0.0193, 0.0809, 0.2809, 0.1084, 0.0892, 0.0350, 0.0170, 0.0007,
@@ -68,9 +85,11 @@ DEFAULT_CLASS_PROPORTIONS = (0.3111, 0.0193, 0.0809, 0.2809, 0.1084, 0.0892, 0.0
 
 def smooth_ce(logits: Tensor, target: Tensor, label_smoothing: float = 0.1, class_w: Optional[Tensor] = None,
               bg_distrib: Optional[Tensor] = None, bg_index: int = 0, want_grad: bool = False,
-              ws: Optional[E.Workspace] = None, loss_out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Tensor]:
-    """One pass of c2s_smooth_ce: returns (loss[1], dlogits | None, counters[2]) -- counters[1] is the number of labels
-    outside [0, K) the pass met (a device value: reading it synchronises)."""
+              ws: Optional[E.Workspace] = None, loss_out: Optional[Tensor] = None, reduction: str = "mean",
+              pixel_loss: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Tensor]:
+    """One pass of c2s_smooth_ce_ex: returns (loss[1], dlogits | None, counters[2]) -- counters[1] is the number of labels
+    outside [0, K) the pass met (a device value: reading it synchronises).  reduction 'mean' | 'sum' | 'none' (the per-pixel
+    terms go to `pixel_loss` [B,H,W]; loss[0] is then their sum and dlogits the gradient of that sum)."""
     if not logits.is_cuda:
         raise RuntimeError("crop2seg_amd runs on MI355X only (no CPU fallback)")
     logits = logits.contiguous()
@@ -80,16 +99,21 @@ def smooth_ce(logits: Tensor, target: Tensor, label_smoothing: float = 0.1, clas
     w = ws.get("smooth_ce", lib().c2s_smooth_ce_workspace_floats())
     loss = loss_out if loss_out is not None else torch.empty(1, device=logits.device, dtype=torch.float32)
     gl = torch.empty_like(logits) if want_grad else None
-    check(lib().c2s_smooth_ce(logits.data_ptr(), target.data_ptr(), E._ptr(class_w), E._ptr(bg_distrib), loss.data_ptr(),
-                              E._ptr(gl), B, K, H, W, float(label_smoothing), int(bg_index), 1 if loss_out is not None else 0,
-                              w.data_ptr(), w.numel(), E._stream()), "smooth_ce")
+    red = {"mean": 0, "sum": 1, "none": 2}[reduction]
+    if red == 2 and pixel_loss is None:
+        raise ValueError("smooth_ce: reduction='none' needs a pixel_loss tensor")
+    check(lib().c2s_smooth_ce_ex(logits.data_ptr(), target.data_ptr(), E._ptr(class_w), E._ptr(bg_distrib), loss.data_ptr(),
+                                 E._ptr(gl), E._ptr(pixel_loss), B, K, H, W, float(label_smoothing), int(bg_index), red,
+                                 1 if loss_out is not None else 0, w.data_ptr(), w.numel(), E._stream()), "smooth_ce")
     return loss, gl, w[w.numel() - 2:]
 
 
 class SmoothCrossEntropy2D:
     """Call-compatible with the reference's criterion (smooth_loss.py:18-84; constructor arguments in the same order):
     label smoothing that follows the field borders -- classes present in the 4-neighbourhood of a pixel share the target
-    mass -- with the fixed distribution for background pixels, then CE with probability targets (reduction 'mean').
+    mass -- with the fixed distribution for background pixels, then CE with probability targets (reduction 'mean' / 'sum' /
+    'none', or the legacy size_average / reduce flags; with 'none' the call returns the [B,H,W] terms and grad() is the gradient of
+    their sum).
     The value carries no autograd graph; `grad()` returns dL/dlogits of the last call with want_grad=True (TrainStep feeds
     it into the tape).  `check_targets()` raises if the last call met labels outside [0, K) -- the reference's one_hot
     raises there; the kernel skips and counts them instead of faulting."""
@@ -98,8 +122,13 @@ class SmoothCrossEntropy2D:
                  reduction: str = "mean", label_smoothing: float = 0.1, background_treatment: bool = True,
                  background_index: int = 0, background_label_value: float = 0.6,
                  class_proportions=DEFAULT_CLASS_PROPORTIONS):
-        if reduction != "mean" or size_average is not None or reduce is not None:
-            raise NotImplementedError("SmoothCrossEntropy2D: only reduction='mean' is built")
+        if size_average is not None or reduce is not None:       # torch.nn._reduction.legacy_get_string
+            size_average = True if size_average is None else size_average
+            reduce = True if reduce is None else reduce
+            reduction = "mean" if (size_average and reduce) else ("sum" if reduce else "none")
+        if reduction not in ("mean", "sum", "none"):
+            raise ValueError(f"{reduction} is not a valid value for reduction")
+        self.reduction = reduction
         self.weight, self.ls = weight, float(label_smoothing)
         self.background_treatment, self.background_index = bool(background_treatment), int(background_index)
         bd = torch.tensor([background_label_value] + list(class_proportions), dtype=torch.float32)
@@ -127,9 +156,11 @@ class SmoothCrossEntropy2D:
             cw = self._w_dev
         if self._ws is None or self._ws.device != input.device:
             self._ws = E.Workspace(input.device)
-        loss, gl, counters = smooth_ce(input, target, self.ls, cw, bg, self.background_index, want_grad, self._ws)
+        pl = torch.empty(target.shape, device=input.device, dtype=torch.float32) if self.reduction == "none" else None
+        loss, gl, counters = smooth_ce(input, target, self.ls, cw, bg, self.background_index, want_grad, self._ws,
+                                       reduction=self.reduction, pixel_loss=pl)
         self._last = (gl, counters)
-        return loss[0]
+        return pl if pl is not None else loss[0]
 
     forward = __call__
 

@@ -514,6 +514,10 @@ int c2s_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr
  *   c2s_boundary_target: y_b = (get_dilated(y, K, connectivity 4).sum(1) > 1): 1 where a 4-neighbour holds another class.
  *   c2s_focal_ce: FocalCELoss(gamma, size_average=True, weight=None): mean over targets != ignore_index of
  *     -(1-pt)^gamma log pt; accumulate_loss != 0 adds it to *loss (utils.py:324 loss = loss + loss_b).
+ *   c2s_focal_ce_ex: the module's other constructor arguments (focal_loss.py:12-45): size_average == 0: the sum; class_w[K]
+ *     non-NULL: the reference multiplies a [N,1] column of gathered weights by the [N] row of focal terms (an N x N outer
+ *     product, focal_loss.py:36-39), i.e. its value is mean_i(w[t_i]) * mean_j(f_j) (sum_i * sum_j without size_average) --
+ *     computed as that product, without the N^2 tensor.
  * ------------------------------------------------------------------------------------------------ */
 int c2s_metrics_update(const float* logits, const long long* target, long long* conf, long long* conf_top2,
                        long long* pred, long long* pred_top2, int B, int K, int HW, void* stream);
@@ -529,6 +533,9 @@ size_t c2s_focal_ce_workspace_floats(void);
 int c2s_focal_ce(const float* logits, const long long* target, float* loss, float* glogits, int B, int K, int HW,
                  float gamma, long long ignore_index, int accumulate_loss, float* workspace, size_t ws_floats,
                  void* stream);
+int c2s_focal_ce_ex(const float* logits, const long long* target, const float* class_w, float* loss, float* glogits, int B,
+                    int K, int HW, float gamma, long long ignore_index, int size_average, int accumulate_loss,
+                    float* workspace, size_t ws_floats, void* stream);
 /* SmoothCrossEntropy2D (smooth_loss.py:18-84): soft targets from the 4-neighbourhood dilation of the label map (classes
  * present at the pixel or a 4-neighbour share 1 - eps*(K - n) evenly, the others get eps = label_smoothing / K; pixels
  * labelled bg_index take bg_distrib[K] instead when it is non-NULL: background_treatment), then CrossEntropyLoss with
@@ -539,6 +546,11 @@ size_t c2s_smooth_ce_workspace_floats(void);
 int c2s_smooth_ce(const float* logits, const long long* target, const float* class_w, const float* bg_distrib, float* loss,
                   float* glogits, int B, int K, int H, int W, float label_smoothing, long long bg_index, int accumulate_loss,
                   float* workspace, size_t ws_floats, void* stream);
+/* the same with CrossEntropyLoss's other reductions: reduction 0 'mean', 1 'sum', 2 'none' -- pixel_loss [B,H,W] (required
+ * for 2, optional otherwise) receives the per-pixel terms; with 2, *loss is their sum and glogits the gradient of that sum */
+int c2s_smooth_ce_ex(const float* logits, const long long* target, const float* class_w, const float* bg_distrib, float* loss,
+                     float* glogits, float* pixel_loss, int B, int K, int H, int W, float label_smoothing, long long bg_index,
+                     int reduction, int accumulate_loss, float* workspace, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch movers on either side of the path.

@@ -41,21 +41,35 @@ def miou_case(name, seed, K, B, H, ignore_index, n_batches, zero_frac):
     print(name, "miou", miou, "acc", acc, "conf sum", int(conf.sum()))
 
 
-def focal_case(name, seed, B, K, H, gamma, ignore_frac):
+def focal_case(name, seed, B, K, H, gamma, ignore_frac, weighted=False, size_average=True):
     g = torch.Generator().manual_seed(seed)
     logits = (2 * torch.randn(B, K, H, H, generator=g)).requires_grad_(True)
     y = torch.randint(0, K, (B, H, H), generator=g)
     if ignore_frac > 0:
         y[torch.rand(B, H, H, generator=g) < ignore_frac] = -100
-    loss = FocalCELoss(gamma=gamma)(logits, y)
+    extra = {}
+    if weighted or not size_average:               # round 4: the module's other constructor arguments (focal_loss.py:12-45)
+        w = (torch.rand(K, generator=g) + 0.5) if weighted else None
+        loss = FocalCELoss(gamma=gamma, size_average=size_average, weight=w)(logits, y)
+        extra = dict(size_average=np.int64(size_average), weight=(w.numpy() if weighted else np.zeros(0, np.float32)))
+    else:
+        loss = FocalCELoss(gamma=gamma)(logits, y)
     loss.backward()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), logits=logits.detach().numpy(), y=y.numpy(),
-                        loss=np.float64(loss.item()), grad=logits.grad.numpy(), gamma=np.float64(gamma))
+                        loss=np.float64(loss.item()), grad=logits.grad.numpy(), gamma=np.float64(gamma), **extra)
     print(name, "loss", loss.item())
+
+
+def round4():
+    focal_case("tail_focal_g2_weighted", 203, 2, 5, 16, 2.0, 0.15, weighted=True)             # [N,1] x [N] broadcast of the reference
+    focal_case("tail_focal_g1_sum", 204, 2, 4, 12, 1.0, 0.1, size_average=False)
+    focal_case("tail_focal_g2_weighted_sum", 205, 1, 3, 12, 2.0, 0.0, weighted=True, size_average=False)
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--round4" in sys.argv:
+        return round4()
     miou_case("tail_miou_k15", 101, 15, 3, 32, -1, 3, 0.4)
     miou_case("tail_miou_k4", 103, 4, 2, 16, -1, 2, 0.7)
     focal_case("tail_focal_g2", 201, 3, 2, 32, 2.0, 0.0)          # iterate(): FocalCELoss(gamma=2.0) on the 2-class boundary head

@@ -93,8 +93,11 @@ def boundary_target(y: torch.Tensor, n_classes: int) -> torch.Tensor:
     return torch.where(get_dilated(y, n_classes, 4).sum(1) > 1, 1, 0)
 
 
-def focal_ce(preds: torch.Tensor, target: torch.Tensor, gamma: float = 2.0, ignore_index: int = -100) -> torch.Tensor:
-    """FocalCELoss.forward with size_average=True, weight=None (focal_loss.py:19-44)."""
+def focal_ce(preds: torch.Tensor, target: torch.Tensor, gamma: float = 2.0, ignore_index: int = -100,
+             weight: Optional[torch.Tensor] = None, size_average: bool = True) -> torch.Tensor:
+    """FocalCELoss.forward (focal_loss.py:19-45).  With class weights the reference gathers them as an [N,1] column and
+    multiplies by the [N] row of focal terms (focal_loss.py:36-39): an N x N outer product whose mean / sum is the product of
+    the means / sums -- restated as that product (the fixtures tail_focal_*weighted* pin it to the imported module)."""
     target = target.reshape(-1, 1)
     if preds.ndim > 2:
         preds = preds.permute(0, 2, 3, 1).flatten(0, 2)
@@ -102,7 +105,11 @@ def focal_ce(preds: torch.Tensor, target: torch.Tensor, gamma: float = 2.0, igno
     preds, target = preds[keep, :], target[keep, :]
     logpt = F.log_softmax(preds, dim=1).gather(1, target).view(-1)
     pt = logpt.exp()
-    return (-1 * (1 - pt) ** gamma * logpt).mean()
+    loss = -1 * (1 - pt) ** gamma * logpt
+    if weight is not None:
+        w = weight[target[:, 0]]
+        return w.mean() * loss.mean() if size_average else w.sum() * loss.sum()
+    return loss.mean() if size_average else loss.sum()
 
 
 def smooth_targets(target: torch.Tensor, n_classes: int, label_smoothing: float = 0.1) -> torch.Tensor:
@@ -131,7 +138,8 @@ DEFAULT_CLASS_PROPORTIONS = (0.3111, 0.0193, 0.0809, 0.2809, 0.1084, 0.0892, 0.0
 
 def smooth_cross_entropy_2d(logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor] = None,
                             label_smoothing: float = 0.1, background_treatment: bool = True, background_index: int = 0,
-                            background_label_value: float = 0.6, class_proportions=DEFAULT_CLASS_PROPORTIONS) -> torch.Tensor:
+                            background_label_value: float = 0.6, class_proportions=DEFAULT_CLASS_PROPORTIONS,
+                            reduction: str = "mean") -> torch.Tensor:
     """SmoothCrossEntropy2D.forward (smooth_loss.py:58-84): dilation soft targets, the background distribution, then
     torch's own CrossEntropyLoss (the reference's superclass) with probability targets.  Parity unpinned: the module
     imports src.learning.utils -> torchnet, which this image lacks; the CE itself is torch's."""
@@ -141,7 +149,7 @@ def smooth_cross_entropy_2d(logits: torch.Tensor, target: torch.Tensor, weight: 
         bd = torch.tensor([background_label_value] + list(class_proportions), dtype=torch.float32)
         bd[1:] *= 1 - background_label_value
         target_out = torch.where(target[:, None, ...] == background_index, bd[:, None, None], target_out)
-    return torch.nn.CrossEntropyLoss(weight=weight)(logits, target_out)
+    return torch.nn.CrossEntropyLoss(weight=weight, reduction=reduction)(logits, target_out)
 
 
 # ------------------------------------------------------------------------------------------------ N1: collate

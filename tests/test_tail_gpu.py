@@ -69,17 +69,29 @@ def test_boundary_target_bit_exact(shape):
     assert torch.equal(boundary_target(y.cuda()).cpu(), TO.boundary_target(y, 15))
 
 
-@pytest.mark.parametrize("name", ["tail_focal_g2", "tail_focal_g1_ignore"])
+@pytest.mark.parametrize("name", ["tail_focal_g2", "tail_focal_g1_ignore", "tail_focal_g2_weighted", "tail_focal_g1_sum",
+                                  "tail_focal_g2_weighted_sum"])
 def test_focal_loss_matches_reference_fixture(name):
-    from crop2seg_amd.learning.losses import focal_ce
+    """Fixtures from the imported src/learning/focal_loss.py; the *_weighted / *_sum ones (round 4) cover the module's class
+    weights -- the reference's [N,1] x [N] broadcast: product of the weight mean / sum and the focal mean / sum -- and
+    size_average=False."""
+    from crop2seg_amd.learning.losses import FocalCELoss, focal_ce
     z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
-    loss, grad = focal_ce(torch.from_numpy(z["logits"]).cuda(), torch.from_numpy(z["y"]).cuda(), float(z["gamma"]), want_grad=True)
-    assert abs(float(loss) - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+    w = torch.from_numpy(z["weight"]) if "weight" in z.files and z["weight"].size else None
+    sa = bool(z["size_average"]) if "size_average" in z.files else True
+    logits, y = torch.from_numpy(z["logits"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    loss, grad = focal_ce(logits, y, float(z["gamma"]), want_grad=True, class_w=w, size_average=sa)
+    assert abs(float(loss) - float(z["loss"])) <= 4e-6 * abs(float(z["loss"]))
     ref = torch.from_numpy(z["grad"])
-    assert float((grad.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert float((grad.cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
     base = torch.full((1,), 0.25, device="cuda")
-    focal_ce(torch.from_numpy(z["logits"]).cuda(), torch.from_numpy(z["y"]).cuda(), float(z["gamma"]), loss_out=base)
-    assert abs(float(base) - 0.25 - float(z["loss"])) <= 1e-5
+    focal_ce(logits, y, float(z["gamma"]), loss_out=base, class_w=w, size_average=sa)
+    assert abs(float(base) - 0.25 - float(z["loss"])) <= 1e-5 * max(1.0, abs(float(z["loss"])))
+    crit = FocalCELoss(gamma=float(z["gamma"]), size_average=sa, weight=w)           # the module-shaped wrapper
+    assert abs(float(crit(logits, y, want_grad=True)) - float(z["loss"])) <= 4e-6 * abs(float(z["loss"]))
+    assert torch.equal(crit.grad(), grad)
+    flat = crit(logits.permute(0, 2, 3, 1).reshape(-1, logits.shape[1]), y.reshape(-1))     # (N, C) logits, (N,) targets
+    assert abs(float(flat) - float(z["loss"])) <= 4e-6 * abs(float(z["loss"]))
 
 
 @pytest.mark.parametrize("eps,ignore", [(0.0, False), (0.1, False), (0.2, True)])
@@ -286,8 +298,9 @@ def test_predict_tile_timeunet_equals_patch_by_patch():
     assert bool((top1.cpu() == rt)[(top2[0] - top2[1]) > 1e-6].all())
 
 
-@pytest.mark.parametrize("bg,weighted", [(True, False), (False, True), (True, True)])
-def test_smooth_cross_entropy_2d(bg, weighted):
+@pytest.mark.parametrize("bg,weighted,reduction", [(True, False, "mean"), (False, True, "mean"), (True, True, "mean"),
+                                                  (True, True, "sum"), (False, True, "none")])
+def test_smooth_cross_entropy_2d(bg, weighted, reduction):
     """N4: SmoothCrossEntropy2D (smooth_loss.py:18-84) -- loss and dL/dlogits against the restatement (dilation soft targets +
     torch's own CrossEntropyLoss with probability targets) differentiated by autograd.  Parity unpinned: the reference
     module cannot be imported here (torchnet)."""
@@ -301,11 +314,16 @@ def test_smooth_cross_entropy_2d(bg, weighted):
     if weighted:
         cw = torch.rand(K, generator=g) + 0.5
         cw[-1] = 0
-    ref = TO.smooth_cross_entropy_2d(logits, y, cw, 0.1, background_treatment=bg)
-    ref.backward()
-    crit = SmoothCrossEntropy2D(weight=cw, label_smoothing=0.1, background_treatment=bg)
+    ref = TO.smooth_cross_entropy_2d(logits, y, cw, 0.1, background_treatment=bg, reduction=reduction)
+    ref.sum().backward()                          # 'none': [B,H,W] terms; grad() is the gradient of their sum
+    crit = SmoothCrossEntropy2D(weight=cw, label_smoothing=0.1, background_treatment=bg, reduction=reduction)
     loss = crit(logits.detach().cuda(), y.cuda(), want_grad=True)
-    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    if reduction == "none":
+        assert loss.shape == ref.shape and float((loss.cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+        legacy = SmoothCrossEntropy2D(weight=cw, reduce=False, label_smoothing=0.1, background_treatment=bg)
+        assert legacy.reduction == "none" and SmoothCrossEntropy2D(size_average=False).reduction == "sum"
+    else:
+        assert abs(float(loss) - float(ref)) <= 4e-6 * abs(float(ref))
     gl = crit.grad().cpu()
     assert float((gl - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
     crit.check_targets()
