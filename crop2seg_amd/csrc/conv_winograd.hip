@@ -519,14 +519,15 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
         t[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
         t[3][q] = g[2][q];
     }
-    if (jb.kind == 2) {          // the 8-wave kernel's layout (conv_winograd16.hip): [cout block][chunk][8 c][64 o][20], 16 used
-        float* wide = jb.dst + ((((size_t)(o >> 6) * nchunks + (c >> 3)) * WN_CK + (c & 7)) * 64 + (o & 63)) * 20;
+    if (jb.kind == 2) {          // the 8-wave kernel's layout (conv_winograd16.hip): [cout block][chunk][8 c][4 xi][64 o][4 nu]
+        float* wide = jb.dst + (((size_t)(o >> 6) * nchunks + (c >> 3)) * WN_CK + (c & 7)) * 64 * 16 + (size_t)(o & 63) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            wide[i * 4 + 0] = t[i][0];
-            wide[i * 4 + 1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-            wide[i * 4 + 2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-            wide[i * 4 + 3] = t[i][2];
+            float* w4 = wide + i * 256;
+            w4[0] = t[i][0];
+            w4[1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+            w4[2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+            w4[3] = t[i][2];
         }
         return;
     }

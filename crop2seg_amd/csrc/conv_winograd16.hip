@@ -7,10 +7,11 @@
 // conv_winograd.hip gives wave xi one ROW of the 4x4 transform domain (8 accumulators of 32x32), so the xi-sum of the output
 // transform crosses waves: three LDS barriers and a 64 KB exchange per tile (10.5 k of its 56 k cycles per tile, with the MFMA
 // pipe of that workgroup idle; tools/wino_stamps.py).  Here a wave owns all 16 points of 32 OUTPUT CHANNELS x 16 BLOCKS:
-//   workgroup = 8 waves on one tile of 64 blocks (8 x 32 output pixels) x 64 output channels; wave w: channels 32 (w & 1) ..,
-//   block row w >> 1;  accumulators acc[16 points][2 channel groups] of 16x16 = 128 VGPRs
-//   A operand = U[p][c][o]   lane (o = lane & 15, k = lane >> 4): the 16 points of one (c, o) are 16 consecutive floats in LDS
-//                            (pitch 20 floats: four conflict-free ds_read_b128)
+//   workgroup = 8 waves on one tile of 64 blocks x 64 output channels; wave w: channels 32 (w & 1) .., 16 blocks of one block
+//   row;  accumulators acc[16 points][2 channel groups] of 16x16 = 128 VGPRs.  The tile is 4 x 16 blocks = 8 x 32 output pixels
+//   (template BR x BC; 2 x 32 was measured and is not instantiated, see the launch).
+//   A operand = U[p][c][o]   lane (o = lane & 15, k = lane >> 4): four ds_read_b128, one per row xi of the 4x4 points; a half slab
+//                            is stored [c][xi][o][nu], so the 16 lanes of a read touch 256 contiguous bytes
 //   B operand = V[p][c][t]   lane (t = lane & 15 = block column, k = lane >> 4) transforms the WHOLE 4x4 patch of its (block,
 //                            channel): four ds_read2_b64, 16 packed VALU ops (v_pk_add_f32), used by 32 MFMAs
 //   D                        lane (t, q): channels 4q .. 4q+3 of block t, for all 16 points -> At M A in registers, one float2
@@ -33,10 +34,17 @@
 
 namespace {
 
+#ifdef C2S_W16_STAMP
+// diagnostic build only (tools/wino16_diag.py --stamps): per workgroup, cycles wave 0 spent between the top of the s_waitcnt in
+// front of the chunk barrier and the instruction after the barrier, the kernel's total, the number of chunks, and the cycles of
+// the epilogues
+__device__ unsigned long long w16_stamps[1024 * 4];
+#endif
+
 struct Wino16Params {
     const float* src0;
     const float* src1;
-    const float* upk;      // [cout block][chunk][8 c][64 o][20] (16 points + 4 pad)
+    const float* upk;      // [cout block][chunk][8 c][4 xi][64 o][4 nu]
     const float* bias;
     float* out;
     const int* valid;
@@ -46,29 +54,37 @@ struct Wino16Params {
 };
 
 constexpr int W16_CK = 8;
-constexpr int W16_UP = 20;                          // floats per (c, o): 16 points + 4 (bank-conflict-free b128 reads)
-constexpr int W16_USLAB = W16_CK * 64 * W16_UP;     // 10,240 floats = 40 KB per chunk
-constexpr int W16_BR = 4, W16_BC = 16;              // blocks per tile: 4 rows x 16 columns = 8 x 32 output pixels
-constexpr int W16_RR = 2 * W16_BR + 2, W16_RC = 2 * W16_BC + 2;     // raw tile 10 x 34
-constexpr int W16_PLANE = W16_RR * W16_RC;          // 340
-constexpr int W16_XP = 352;                         // LDS pitch per channel (= 32 mod 64 banks: the four k groups of a wave do not collide)
-constexpr int W16_MAXE = 6;                         // raw-tile LDS-DMA pieces per thread (one float each)
-constexpr int W16_XS = W16_MAXE * 512;              // 3,072 floats: 8 x 352 and a zero-filled tail
-constexpr int W16_UHALF = W16_USLAB / 2;            // a k-step's half slab (4 channels): 20 KB; ring of five
-constexpr int W16_URING = 5 * W16_UHALF;            // 100 KB
-constexpr int W16_XSLOTS = 4;                       // raw-tile ring: 48 KB
-constexpr int W16_LDS_FLOATS = W16_URING + W16_XSLOTS * W16_XS + 64;     // + the bias of the 64 channels: 151,808 B (+ frame flag bits)
-constexpr int W16_WPT = W16_USLAB / 4 / 512;        // 5 LDS-DMA pieces per thread
+constexpr int W16_UP = 16;                          // floats per (c, o): the 16 points, stored [c][xi 4][o 64][nu 4] (see the pack kernel)
+constexpr int W16_USLAB = W16_CK * 64 * W16_UP;     // 8,192 floats = 32 KB per chunk
+constexpr int W16_UHALF = W16_USLAB / 2;            // a k-step's half slab (4 channels): 16 KB; ring of five
+constexpr int W16_URING = 5 * W16_UHALF;            // 80 KB
+constexpr int W16_XSLOTS = 4;                       // raw-tile ring
+constexpr int W16_WPT = W16_USLAB / 4 / 512;        // 4 LDS-DMA pieces per thread: two per half slab
+// tile of BR x BC blocks of 2 x 2 output pixels (BR * BC = 64: one block row of 16 blocks per wave and channel half)
+template <int BR, int BC>
+struct W16Shape {
+    static_assert(BR * BC == 64 && BC % 16 == 0, "eight waves: 2 channel halves x BR block rows x BC / 16 column groups");
+    static constexpr int RR = 2 * BR + 2, RC = 2 * BC + 2;          // raw tile: 10 x 34 (4 x 16 blocks), 6 x 66 (2 x 32)
+    static constexpr int PLANE = RR * RC;                           // 340 / 396
+    static constexpr int XP = (PLANE + 31) / 64 * 64 + 32;          // LDS pitch per channel >= PLANE, = 32 mod 64 banks (the four
+                                                                    // k groups of a wave do not collide): 352 / 416
+    static constexpr int MAXE = (W16_CK * XP + 511) / 512;          // raw-tile LDS-DMA pieces per thread (one float each): 6 / 7
+    static constexpr int XS = MAXE * 512;                           // floats per raw slot (8 x XP and a zero-filled tail)
+    static constexpr int LDS_FLOATS = W16_URING + W16_XSLOTS * XS + 64;     // + the bias of the 64 channels: 131,328 / 139,520 B
+};                                                                          // (+ frame flag bits)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // tools/wino16_diag.py builds diagnostic copies with one part of the kernel removed (results are then wrong by design):
 //   1 = no MFMA, 2 = no staging after the first two chunks, 3 = no output stores, 4 = no LDS operand reads in the K loop,
 //   5 = 2 and 4 together (MFMA + transform + epilogue only), 6 = 5 without the barrier per chunk, 7 = 5 without the transforms,
-//   8 = no raw-tile staging, 9 = no U staging, 10 = every raw tile from frame 0 (L2 hits)
+//   8 = no raw-tile staging, 9 = no U staging, 10 = every raw tile from frame 0 (L2 hits), 11 = 7 without the epilogue,
+//   12 = 11 without the barrier per chunk (the MFMA loop and the tile walk alone), 13 = raw rows shifted by one float onto a
+//   128-byte line (one line less per row), 14 = raw rows of exactly one line
 #ifndef C2S_W16_DIAG
 #define C2S_W16_DIAG 0
 #endif
+#define C2S_W16_BARE (C2S_W16_DIAG == 11 || C2S_W16_DIAG == 12)       // 7-like: nothing but MFMAs in the K loop
 #define C2S_AS1 __attribute__((address_space(1)))
 #define C2S_AS3 __attribute__((address_space(3)))
 
@@ -82,13 +98,17 @@ __device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b, f32x2 c) {
     return r;
 }
 
-template <bool ADJ>
+template <bool ADJ, int BR, int BC>
 __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p) {
+    using SH = W16Shape<BR, BC>;
+    constexpr int W16_RC = SH::RC, W16_PLANE = SH::PLANE, W16_XP = SH::XP, W16_MAXE = SH::MAXE, W16_XS = SH::XS;
+    constexpr int W16_BR = BR, W16_BC = BC;
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: row masks and bases in SGPRs)
     const int t = lane & 15, kq = lane >> 4;        // block column / k index (B, D: channel quad) ; A: output channel / k index
-    const int ch = w & 1, brow = w >> 1;            // channel half (32) and block row of this wave
+    const int ch = w & 1, brow = (w >> 1) % BR, bcol0 = 16 * ((w >> 1) / BR);      // channel half (32), block row and first block
+                                                                                  // column of this wave
     const int co0 = blockIdx.y * 64;
     const int HW = p.H * p.W;
     const bool reflect = p.pad_mode == C2S_PAD_REFLECT;
@@ -107,6 +127,10 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
         lvalid[wi] = m;
     }
     __syncthreads();
+#ifdef C2S_W16_STAMP
+    unsigned long long st_wait = 0, st_epi = 0, st_chunks = 0, st_first = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     auto next_valid = [&](int tt) {
         while (tt < ntotal) {
             const int f = tt / p.tiles;
@@ -136,6 +160,11 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
             const int e = tid + i * 512;
             const int c = e / W16_XP, rem = e - c * W16_XP;
             int gy = oy0 - 1 + rem / W16_RC, gx = ox0 - 1 + rem % W16_RC;
+            if (C2S_W16_DIAG == 13) gx += 1;
+            if (C2S_W16_DIAG == 14) gx = ox0 + (rem % W16_RC < 32 ? rem % W16_RC : 31);
+            if (C2S_W16_DIAG == 15 && gx < ox0) gx = ox0;                                  // no left halo column
+            if (C2S_W16_DIAG == 16 && gx >= ox0 + 2 * W16_BC) gx = ox0 + 2 * W16_BC - 1;     // no right halo column
+            if (C2S_W16_DIAG == 17) { if (gx < ox0) gx = ox0; if (gx >= ox0 + 2 * W16_BC) gx = ox0 + 2 * W16_BC - 1; }     // neither
             const bool ok = rem < W16_PLANE && c < W16_CK &&
                             (reflect ? (gy <= p.H && gx <= p.W) : (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W));
             gy = reflect_idx(gy, p.H);                    // (identity inside the plane)
@@ -147,10 +176,9 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
         r0 = __builtin_amdgcn_make_buffer_rsrc((void*)s0n, 0, p.C0 * HW * 4, 0x00020000);
         r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(s1n != nullptr ? s1n : s0n), 0, p.C1 * HW * 4, 0x00020000);
     };
-    // both operands by LDS-DMA.  U: 40 KB per chunk, packed lane-linear.  Raw tile: one float per lane and piece, lane-linear in
+    // both operands by LDS-DMA.  U: 32 KB per chunk, packed lane-linear.  Raw tile: one float per lane and piece, lane-linear in
     // LDS, gathered (reflected) global addresses; out-of-range offsets (-1: zero padding, tile overhang, the tail) read as 0
-    // U chunk k -> half slabs h0 and h0 + 1 (mod 5) of the ring; the 40 KB are contiguous in global memory, piece 2 straddles
-    // the halves at a wave boundary (waves 0-3 | 4-7)
+    // U chunk k -> half slabs h0 and h0 + 1 (mod 5) of the ring; the 32 KB are contiguous in global memory, two pieces per half
     // (addresses of the requests: LDS destinations and channel offsets are wave-uniform and stay in scalar registers -- a
     // VALU instruction costs the SIMD ~8 cycles of MFMA issue, see the header)
     auto stage_u = [&](int k, int h0) {
@@ -158,12 +186,11 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
         const int h1 = h0 == 4 ? 0 : h0 + 1;
         const C2S_AS1 char* g = (const C2S_AS1 char*)p.upk + ((size_t)blockIdx.y * K + k) * (W16_USLAB * 4);
         float* d0 = lds + h0 * W16_UHALF + w * 256;
-        float* d1 = lds + h1 * W16_UHALF + w * 256 - W16_UHALF;
+        float* d1 = lds + h1 * W16_UHALF + w * 256;
 #pragma unroll
-        for (int i = 0; i < W16_WPT; ++i) {
-            float* dst = (i < 2 || (i == 2 && w < 4)) ? d0 : d1;
-            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 8192 + (unsigned)(tid * 16)), (C2S_AS3 void*)(dst + i * 2048), 16, 0, 0);
-        }
+        for (int i = 0; i < W16_WPT; ++i)
+            __builtin_amdgcn_global_load_lds((const C2S_AS1 void*)(g + i * 8192 + (unsigned)(tid * 16)),
+                                             (C2S_AS3 void*)((i < 2 ? d0 : d1) + (i & 1) * 2048), 16, 0, 0);
     };
     auto stage_raw = [&](int k, int slot) {
         if (C2S_W16_DIAG == 8 && diag_staged >= 2) return;
@@ -186,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     // Requests (uniform across the workgroup).  The raw tile comes from HBM and is requested THREE chunks ahead of the MFMAs
     // (tools/wino16_diag.py: with two, ~130 us of the 64->64 @128^2 launch were waits for it), U (L2 hits) two ahead.  The U
     // chunk to request next is the one the raw side requested a step earlier: (u_ok, u_k).
-    const bool diag_stage = (C2S_W16_DIAG != 2 && C2S_W16_DIAG < 5);
+    const bool diag_stage = (C2S_W16_DIAG != 2 && (C2S_W16_DIAG < 5 || (C2S_W16_DIAG >= 13 && C2S_W16_DIAG <= 17)));
     bool u_ok = false, young_raw = false;
     int u_k = 0;
     auto stage_next_u = [&](int h0) {
@@ -211,20 +238,20 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     stage_next_raw(2);
 
     // LDS offsets of this lane's operands inside a buffer
-    const int aoff = (kq * 64 + 32 * ch + t) * W16_UP;                          // in a half slab; + mt * 16 * UP
-    const int boff = W16_URING + kq * W16_XP + (2 * brow) * W16_RC + 2 * t;     // in a raw slot; + s * 4 * XP + r * RC
+    const int aoff = kq * (4 * 64 * 4) + (32 * ch + t) * 4;                     // in a half slab [c 4][xi 4][o 64][nu 4]; + mt * 64 + xi * 256
+    const int boff = W16_URING + kq * W16_XP + (2 * brow) * W16_RC + 2 * (bcol0 + t);     // in a raw slot; + s * 4 * XP + r * RC
     auto load_a = [&](const float* ab, int mt, float (&a)[16]) {                 // ab: this lane's row of a half slab
-        if (C2S_W16_DIAG >= 4 && C2S_W16_DIAG <= 7 && ab != lds + aoff) return;
+        if (((C2S_W16_DIAG >= 4 && C2S_W16_DIAG <= 7) || C2S_W16_BARE) && ab != lds + aoff) return;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ab + mt * 16 * W16_UP + 4 * q4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ab + mt * 64 + q4 * 256);       // (16 lanes: 256 contiguous bytes)
             a[4 * q4] = v[0]; a[4 * q4 + 1] = v[1]; a[4 * q4 + 2] = v[2]; a[4 * q4 + 3] = v[3];
         }
     };
     int boff0 = boff, boff1 = boff + 4 * W16_XP;       // (the two k-steps; opaque, so that the row offsets stay ds_read2 immediates)
     asm volatile("" : "+v"(boff0), "+v"(boff1));
     auto load_d = [&](const float* bufp, int s, f32x2 (&dl)[4], f32x2 (&dh)[4]) {     // patch rows as (cols 0,1), (cols 2,3)
-        if (C2S_W16_DIAG >= 4 && C2S_W16_DIAG <= 7 && bufp != lds) return;
+        if (((C2S_W16_DIAG >= 4 && C2S_W16_DIAG <= 7) || C2S_W16_BARE) && bufp != lds) return;
         const float* bb = bufp + (s ? boff1 : boff0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -320,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
         int n, oy0, ox0;
         tile_origin(tile, n, oy0, ox0);
         if constexpr (ADJ) {
-            const int gbx = (ox0 >> 1) + t, gby = (oy0 >> 1) + brow, lastx = (p.W >> 1) - 1, lasty = (p.H >> 1) - 1;
+            const int gbx = (ox0 >> 1) + bcol0 + t, gby = (oy0 >> 1) + brow, lastx = (p.W >> 1) - 1, lasty = (p.H >> 1) - 1;
             mleft = (f32x2){0.f, gbx == 0 ? 1.f : 0.f};
             mright = (f32x2){gbx == lastx ? 1.f : 0.f, 0.f};
             mtop = gby == 0 ? 1.f : 0.f;
@@ -333,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
             const float* xb = lds + rc * W16_XS;
             load_a(lds + u0 * W16_UHALF + aoff, 1, a1);
             __builtin_amdgcn_sched_barrier(0);
-            if (C2S_W16_DIAG != 7 || first) transform(dl, dh, V);
+            if ((C2S_W16_DIAG != 7 && !C2S_W16_BARE) || first) transform(dl, dh, V);
             __builtin_amdgcn_sched_barrier(0);
             load_d(xb, 1, el, eh);                     // (after the transform: its temporaries are dead)
             __builtin_amdgcn_sched_barrier(0);
@@ -345,17 +372,25 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
             __builtin_amdgcn_sched_barrier(0);
             // everyone's requests for the NEXT chunk have landed (U: issued one chunk ago; raw: two); the six youngest (the
             // raw pieces of the chunk after next) may stay in flight -- loads complete in order
-            if (C2S_W16_DIAG != 6) {
-                if (young_raw) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+#ifdef C2S_W16_STAMP
+            const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (C2S_W16_DIAG != 6 && C2S_W16_DIAG != 12) {
+                if (young_raw) __builtin_amdgcn_s_waitcnt(0x0F70 | W16_MAXE);       // vmcnt(6) / vmcnt(7): the raw pieces of a chunk
                 else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
                 __builtin_amdgcn_s_barrier();
             }
+#ifdef C2S_W16_STAMP
+            st_wait += __builtin_amdgcn_s_memtime() - st_t0;
+            if (first) st_first += __builtin_amdgcn_s_memtime() - st_t0;
+            ++st_chunks;
+#endif
             __builtin_amdgcn_sched_barrier(0);
             stage_next_u(u0 == 0 ? 4 : u0 - 1);        // chunk after next: half slabs u0 + 4, u0 + 5 = u0 (mod 5)
             stage_next_raw((rc + 3) & 3);
             load_a(lds + u1 * W16_UHALF + aoff, 1, a1);
             __builtin_amdgcn_sched_barrier(0);
-            if (C2S_W16_DIAG != 7) transform(el, eh, V);
+            if (C2S_W16_DIAG != 7 && !C2S_W16_BARE) transform(el, eh, V);
             mma(a0, V, 0, false);
             __builtin_amdgcn_sched_barrier(0);
             load_a(lds + u2 * W16_UHALF + aoff, 0, a0);                  // (after the last chunk of the last tile: stale, unused)
@@ -368,16 +403,30 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
         };
         chunk(true);
         for (int k = 1; k < K; ++k) chunk(false);
+#ifdef C2S_W16_STAMP
+        const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_nop 7\n\ts_nop 7");             // the last MFMA results are readable by the asm adds of the epilogue
         __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue: At M A per (channel, block) in registers, on channel PAIRS (the accumulator's adjacent registers:
         // v_pk_add_f32), transposed to (column 0, column 1) for one 8-byte store per output row; lane (t, kq): channels
         // cof + 16 mt + r, block (brow, t).  Buffer stores: the channel offset is scalar, an out-of-plane lane or a padded
         // channel is an out-of-range offset -- no address arithmetic or lane masks in the vector ALU
-        const int oy = oy0 + 2 * brow, ox = ox0 + 2 * t;
+        const int oy = oy0 + 2 * brow, ox = ox0 + 2 * (bcol0 + t);
         const __amdgpu_buffer_rsrc_t ro =
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)n * p.Cout * HW), 0, p.Cout * HW * 4, 0x00020000);
         const bool in0 = ox < p.W && oy < p.H && C2S_W16_DIAG != 3, in1 = in0 && oy + 1 < p.H;
+#if C2S_W16_BARE
+        {   // no output transform, no stores: one dependent use keeps the accumulators alive
+            float keepalive = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) keepalive += acc[q][0][0] + acc[q][1][0];
+            if (keepalive == 12345.678f) p.out[0] = keepalive;
+        }
+        if (stile >= ntotal) break;
+        tile = stile;
+        continue;
+#endif
         const int vo0 = in0 ? (cof * HW + oy * p.W + ox) * 4 : 0x7FFF0000;
         const int vo1 = in1 ? vo0 + p.W * 4 : 0x7FFF0000;
 #pragma unroll
@@ -418,9 +467,20 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
                 }
             }
         }
+#ifdef C2S_W16_STAMP
+        st_epi += __builtin_amdgcn_s_memtime() - st_e0;
+#endif
         if (stile >= ntotal) break;
         tile = stile;
     }
+#ifdef C2S_W16_STAMP
+    if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
+        w16_stamps[blockIdx.x * 4 + 0] = st_wait;
+        w16_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime() - st_begin;
+        w16_stamps[blockIdx.x * 4 + 2] = st_chunks | (st_first << 20);
+        w16_stamps[blockIdx.x * 4 + 3] = st_epi;
+    }
+#endif
 }
 
 struct TapTable9w {
@@ -447,25 +507,32 @@ __global__ void pack_winograd16_kernel(const float* __restrict__ src, float* __r
         tmp[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
         tmp[3][j] = g[2][j];
     }
-    float* base = upk + (((size_t)(o >> 6) * nchunks + (c >> 3)) * W16_CK + (c & 7)) * 64 * W16_UP + (size_t)(o & 63) * W16_UP;
+    // row xi of the 4x4 points of (c, o) at [c][xi][o][nu]: the 16 lanes of an MFMA operand read (16 consecutive output channels,
+    // one xi) touch 256 contiguous bytes -- conflict-free without the four floats of padding per (c, o) that round 3 carried
+    float* base = upk + (((size_t)(o >> 6) * nchunks + (c >> 3)) * W16_CK + (c & 7)) * 64 * W16_UP + (size_t)(o & 63) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        base[i * 4 + 0] = tmp[i][0];
-        base[i * 4 + 1] = 0.5f * (tmp[i][0] + tmp[i][1] + tmp[i][2]);
-        base[i * 4 + 2] = 0.5f * (tmp[i][0] - tmp[i][1] + tmp[i][2]);
-        base[i * 4 + 3] = tmp[i][2];
+        float* b4 = base + i * 256;
+        b4[0] = tmp[i][0];
+        b4[1] = 0.5f * (tmp[i][0] + tmp[i][1] + tmp[i][2]);
+        b4[2] = 0.5f * (tmp[i][0] - tmp[i][1] + tmp[i][2]);
+        b4[3] = tmp[i][2];
     }
-#pragma unroll
-    for (int i = 16; i < W16_UP; ++i) base[i] = 0.f;
 }
 
 void init_hook() {
-    C2S_RAISE_LDS((conv_winograd16_kernel<false>));
-    C2S_RAISE_LDS((conv_winograd16_kernel<true>));
+    C2S_RAISE_LDS((conv_winograd16_kernel<false, 4, 16>));
+    C2S_RAISE_LDS((conv_winograd16_kernel<true, 4, 16>));
 }
 C2sInitRegistrar registrar(init_hook);
 
 }  // namespace
+
+#ifdef C2S_W16_STAMP
+extern "C" int c2s_debug_w16_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w16_stamps), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t c2s_winograd16_packed_floats(int cin, int coutP) {
     return (size_t)((cin + W16_CK - 1) / W16_CK) * W16_CK * coutP * W16_UP;
@@ -506,8 +573,11 @@ extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0,
     p.src0 = src0; p.src1 = src1; p.upk = upk; p.bias = bias; p.out = out; p.valid = valid;
     p.C0 = d->C0; p.C1 = d->C1; p.H = d->Hin; p.W = d->Win; p.Cout = d->Cout; p.CoutP = d->CoutP;
     p.pad_mode = d->pad_mode; p.accumulate = d->accumulate;
-    p.tiles_x = cdiv(d->Win, 2 * W16_BC);
-    p.tiles = p.tiles_x * cdiv(d->Hin, 2 * W16_BR);
+    // tile shape: 4 x 16 blocks = 8 x 32 output pixels (the kernel is a template on it; 2 x 32 blocks = 4 x 64 pixels, with one
+    // 66-float raw row per request instead of two of 34, measured 696 / 755 us against 684 / 742 on the 64 -> 64 @128^2 layer)
+    constexpr int BRh = 4, BCh = 16;
+    p.tiles_x = cdiv(d->Win, 2 * BCh);
+    p.tiles = p.tiles_x * cdiv(d->Hin, 2 * BRh);
     p.N = d->N;
     p.nchunks = cdiv(d->C0 + d->C1, W16_CK);
     const int cus = c2s_cus();                     // (runs the init hooks: dynamic LDS limit)
@@ -516,10 +586,10 @@ extern "C" int c2s_conv3x3_winograd16(const c2s_conv_desc* d, const float* src0,
     long gx = ((long)cus + cblocks - 1) / cblocks;  // persistent: one 8-wave workgroup per CU
     if (gx > ntotal) gx = ntotal;
     dim3 grid((unsigned)gx, cblocks, 1);
-    const size_t ldsb = (size_t)(W16_LDS_FLOATS + (d->N + 31) / 32) * sizeof(float);
+    const size_t ldsb = (size_t)(W16Shape<BRh, BCh>::LDS_FLOATS + (d->N + 31) / 32) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (d->reflect_adjoint) hipLaunchKernelGGL((conv_winograd16_kernel<true>), grid, dim3(512), ldsb, st, p);
-    else hipLaunchKernelGGL((conv_winograd16_kernel<false>), grid, dim3(512), ldsb, st, p);
+    if (d->reflect_adjoint) hipLaunchKernelGGL((conv_winograd16_kernel<true, BRh, BCh>), grid, dim3(512), ldsb, st, p);
+    else hipLaunchKernelGGL((conv_winograd16_kernel<false, BRh, BCh>), grid, dim3(512), ldsb, st, p);
     C2S_CHECK_LAUNCH("conv3x3_winograd16");
     return C2S_OK;
 }
