@@ -8,7 +8,7 @@ import sys
 
 d, out = sys.argv[1], sys.argv[2]
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "conv_winograd16_kernel<false>" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "conv_winograd16_kernel<false" in r["Kernel_Name"]]      # (<false> in round 3, <false, 4, 16> since the shape template)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 big = max(durs)

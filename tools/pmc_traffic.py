@@ -94,8 +94,8 @@ def parse(dir_fetch, dir_write):
     f_dword = (2.0 * ADD_FLOATS * 4) / add_f            # known bytes / reported bytes, dword-per-lane reads
     f_b128 = act / rs_f                                 # 16-B-per-lane reads
     f_store = (ADD_FLOATS * 4.0) / add_w                # dword-per-lane stores
-    wide = any("conv_winograd16_kernel<false>" in k for k in fetch)      # the default for planes >= 32 wide (C2S_WINO16)
-    needle, key = ("conv_winograd16_kernel<false>", "conv_winograd16_kernel<false>") if wide else \
+    wide = any("conv_winograd16_kernel<false" in k for k in fetch)      # the default for planes >= 32 wide (C2S_WINO16)
+    needle, key = ("conv_winograd16_kernel<false", "conv_winograd16_kernel<false>") if wide else \
                   ("conv_winograd_kernel<4, false>", "conv_winograd_kernel<4,false>")
     wk, (wf, nf) = pick(fetch, needle)
     _, (ww, nw) = pick(write, needle)
