@@ -487,7 +487,7 @@ struct TapTable9w {
     int off[9];
 };
 
-// U = G g Gt of the 3x3 filter g[k] = src[o*so + c*sc + tap[k]], stored [cout block][chunk][c 8][o 64][20]
+// U = G g Gt of the 3x3 filter g[k] = src[o*so + c*sc + tap[k]], stored [cout block][chunk][c 8][xi 4][o 64][nu 4]
 __global__ void pack_winograd16_kernel(const float* __restrict__ src, float* __restrict__ upk, int cin, int cout, int coutP,
                                        long so, long sc, TapTable9w tt) {
     const int nchunks = (cin + W16_CK - 1) / W16_CK;

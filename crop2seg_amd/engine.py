@@ -339,7 +339,7 @@ def _pack_bf16x3(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, co
 def _pack_winograd(ctx: "Ctx", key: Tuple, src: Tensor, src_off: int, cin: int, cout: int, so: int, sc: int,
                    taps: Sequence[int], wide: bool = False) -> Tuple[Tensor, int]:
     """U = G g Gt of every 3x3 filter, [16][cin][coutP] (cached per forward); `wide` = the layout of the 8-wave kernel
-    (conv_winograd16.hip: [cout block][chunk][8 c][64 o][20])."""
+    (conv_winograd16.hip: [cout block][chunk][8 c][4 xi][64 o][4 nu])."""
     hit = ctx._packed.get(key)
     coutP = (cout + 63) // 64 * 64
     if hit is not None:
@@ -517,7 +517,7 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
     KK = K * K
     out = torch.empty(N, Cout, Ho, Wo, device=s0.device, dtype=torch.float32)
     if _use_winograd(K, S, pad, [C0, C1] if C1 else [C0], Cout, Hin, Win):
-        wide = _wide_winograd(Hin, Win, [C0, C1] if C1 else [C0]) and N <= 30720
+        wide = _wide_winograd(Hin, Win, [C0, C1] if C1 else [C0]) and N <= 65536
         upk, CoutP = _pack_winograd(ctx, (wname, "fwd", "wino"), W, 0, Cin, Cout, Cin * KK, KK, list(range(KK)), wide)
         d = ConvDesc(N, C0, C1, Hin, Win, Cout, CoutP, Ho, Wo, Ho, Wo, K, K, S, pad, pad, pad_mode, 1, 1, 0, 0, 0)
         _winograd(d, s0, s1, upk, ctx.p[bname] if bname else None, out, valid, wide)
@@ -575,7 +575,7 @@ def conv2d(ctx: Ctx, srcs: Sequence[Tensor], wname: str, bname: Optional[str], K
             if S == 1:
                 taps = [(K - 1 - ky) * K + (K - 1 - kx) for ky in range(K) for kx in range(K)]
                 if _use_winograd(K, S, pad, [Cout], Cs, Hin, Win):
-                    wide = _wide_winograd(Hin, Win, [Cout]) and N <= 30720
+                    wide = _wide_winograd(Hin, Win, [Cout]) and N <= 65536
                     upk, CP = _pack_winograd(ctx, (wname, "dgrad", "wino", si), W, c_lo * KK, Cout, Cs, KK, Cin * KK, taps, wide)
                     dd = ConvDesc(N, Cout, 0, Ho, Wo, Cs, CP, Hin, Win, Hin, Win, K, K, 1, 1, 1, _lib.PAD_ZEROS, 1, 1, 0, 0,
                                   accf, radj)

@@ -146,7 +146,8 @@ int c2s_conv3x3_winograd(const c2s_conv_desc* d, const float* src0, const float*
  * The same Winograd F(2x2,3x3) convolution on v_mfma_f32_16x16x4_f32 with the output transform in registers (8-wave
  * workgroups, 8 x 32 pixel tiles; conv_winograd16.hip) for planes at least 32 wide and 8 high.  Same descriptor and
  * semantics as c2s_conv3x3_winograd; upk = c2s_pack_weights_winograd16 (c2s_winograd16_packed_floats(Cin, CoutP) floats,
- * [cout block of 64][chunk of 8 input channels][8][64][20]).  c2s_conv3x3_winograd16_supported = the host-side predicate.
+ * [cout block of 64][chunk of 8 input channels][8 c][4 xi][64 o][4 nu]).  c2s_conv3x3_winograd16_supported = the host-side
+ * predicate.
  * ------------------------------------------------------------------------------------------------ */
 size_t c2s_winograd16_packed_floats(int cin, int coutP);
 int c2s_pack_weights_winograd16(const float* src, float* upk, int cin, int cout, int coutP, long stride_o, long stride_c,
