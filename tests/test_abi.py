@@ -92,7 +92,7 @@ def test_winograd_family_predicates_without_gpu():
         assert L.c2s_conv4x4s2_dgrad_winograd_supported(ctypes.byref(bad)) == 0
     assert L.c2s_conv4x4s2_dgrad_winograd(ctypes.byref(dg(kc=16)), 16, 16, 16, None, None) == -1
     assert L.c2s_s2wino_packed_floats(64, 64) == 32 * 2 * 4 * 64 * 12 and L.c2s_s2dgrad_packed_floats(64, 64) == 4 * 64 * 64 * 12
-    assert L.c2s_winograd16_packed_floats(64, 64) == 8 * 8 * 64 * 20
+    assert L.c2s_winograd16_packed_floats(64, 64) == 8 * 8 * 64 * 16       # 16 points per (c, o): no padding since round 4
 
 
 @pytest.mark.parametrize("name", ["utae_eval_pad_wi", "timeunet_eval_pad_wi", "wtae_eval_pad_wi"])
