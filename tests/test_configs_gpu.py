@@ -337,3 +337,29 @@ def test_c5_shape_hipgraph_replay_equals_eager():
     assert float(loss_g) == loss_e and loss_e == loss_e
     assert torch.equal(step_g.flat_param, param_e)
     assert int(step_g.step_dev) == 3 and step_g.ws.sync_error() == 0
+
+
+@pytest.mark.parametrize("model,B,T,H,frac", [("utae", 2, 6, 64, 0.85), ("wtae", 2, 6, 64, 0.85), ("timeunet", 2, 8, 128, 0.95)])
+def test_repeated_steps_on_a_learnable_batch_reduce_the_loss(model, B, T, H, frac):
+    """End-to-end sanity of the train step as a whole (forward, CE, every backward kernel, the flat Adam) that no single-step
+    parity test gives: forty steps on one batch whose labels are a function of the input (arg max of a fixed random projection of
+    each pixel's temporal mean) must bring the loss well below its start, with finite parameters -- eager steps, then the same
+    through hipGraph replays of the captured step.  TimeUNet at 128 x 128 takes the register-resident / streaming L-TAE kernels."""
+    C2S, L, E, Fn, LU, synthetic_batch = _mods()
+    x, dates, _, _ = synthetic_batch(B, T, H, H, 3, "cuda", lengths=[T, T - 2])
+    g = torch.Generator().manual_seed(7)
+    proj = torch.randn(15, 10, generator=g).cuda()
+    nvalid = torch.tensor([T, T - 2], device="cuda").view(B, 1, 1, 1).float()
+    y = torch.einsum("kc,bchw->bkhw", proj, x.sum(dim=1) / nvalid).argmax(dim=1)
+    if model == "timeunet":
+        assert _streams(B, T, 64, H * H)
+    net = _model(model, "wi", seed=3).train()
+    step = LU.TrainStep(net, num_classes=15, lr=2e-3)
+    losses = [float(step(x, dates, y)[0]) for _ in range(40)]
+    assert all(l == l and l < 1e3 for l in losses), losses
+    assert min(losses[-5:]) < frac * losses[0], (losses[0], losses[-5:])       # (forty steps: U-TAE reaches 0.5, W-TAE 0.76, TimeUNet 0.935 of the start)
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    step.capture(x, dates, y)
+    replayed = [float(step.replay()[0]) for _ in range(10)]
+    assert all(l == l for l in replayed) and min(replayed[-3:]) < frac * losses[0], (losses[-1], replayed)
+    assert min(replayed) <= 1.05 * min(losses[-5:]) + 0.05
