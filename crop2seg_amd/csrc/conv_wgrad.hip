@@ -442,6 +442,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(WgradParams p) 
 // operands are transformed on the fly by the lane that feeds them (its channel's patch rows / gradient block come as
 // ds_read_b64 from channel-major LDS tiles whose pitch is 2*odd mod 64 banks: conflict-free).  The next tile is
 // prefetched into registers under the MFMA loop (single LDS buffer, two barriers per tile), as in the direct kernel.
+#ifdef C2S_WW_STAMP
+// diagnostic build only (tools/wgrad_stamps.py): per workgroup, wave 0's cycles in commit + barrier, in the MFMA loop, at the
+// barrier behind the loop, and in all
+__device__ unsigned long long ww_stamps[1024 * 4];
+#endif
 constexpr int WW_XP = 206;     // raw input tile pitch per channel: 6 x 34 = 204 -> 206 (= 2*7 mod 64)
 constexpr int WW_GP = 130;     // gout tile pitch per channel:      4 x 32 = 128 -> 130 (= 2*1 mod 64)
 
@@ -649,13 +654,24 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
     // adjacent tiles (shared halo rows) meet in one L2; the slab index stays the workgroup index
     int tile = next_tile((p.nslices & 7) == 0 ? (slice & 7) * (p.nslices >> 3) + (slice >> 3) : slice);
     if (tile < p.ntiles) prefetch(tile);
+#ifdef C2S_WW_STAMP
+    unsigned long long st_commit = 0, st_loop = 0, st_tail = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     while (tile < p.ntiles) {
         // the next tile's frame flag is fetched under the LDS commit and the barrier (read right after the barrier it stalled
         // every wave of the workgroup for a memory round trip per tile)
         const int cand = tile + p.nslices;
         const int cflag = (p.valid != nullptr && cand < p.ntiles) ? p.valid[cand / (p.tiles_x * p.tiles_y)] : 1;
+#ifdef C2S_WW_STAMP
+        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+#endif
         commit();
         __syncthreads();
+#ifdef C2S_WW_STAMP
+        const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+        st_commit += st_b - st_a;
+#endif
         const int nxt = cflag != 0 ? cand : next_tile(cand + p.nslices);
         if (nxt < p.ntiles) prefetch(nxt);          // in flight during the MFMA loop below
         f32x2w d[2][4], g[2][2][2];
@@ -698,9 +714,24 @@ __global__ __launch_bounds__(256 * CB, CB == 1 ? 2 : 1) void conv_wgrad_winograd
                     if (v + m > 0) acc[v][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v], Mt[m][v], acc[v][m], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef C2S_WW_STAMP
+        const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+        st_loop += st_c - st_b;
+#endif
         __syncthreads();
+#ifdef C2S_WW_STAMP
+        st_tail += __builtin_amdgcn_s_memtime() - st_c;
+#endif
         tile = nxt;
     }
+#ifdef C2S_WW_STAMP
+    if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0 && blockIdx.z == 0) {
+        ww_stamps[blockIdx.x * 4 + 0] = st_commit;
+        ww_stamps[blockIdx.x * 4 + 1] = st_loop;
+        ww_stamps[blockIdx.x * 4 + 2] = st_tail;
+        ww_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - st_begin;
+    }
+#endif
 
     // ---- dW = Gt dU G inside the workgroup (16 -> 9 values per (cin, cout): 44 % less slab traffic and no separate
     // transform launch): the nu direction is lane-local, the xi direction goes through LDS, one kx column per round.
@@ -1097,6 +1128,12 @@ void init_hook() {
 C2sInitRegistrar registrar(init_hook);
 
 }  // namespace
+
+#ifdef C2S_WW_STAMP
+extern "C" int c2s_debug_ww_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ww_stamps), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int c2s_wgrad_algorithms(int winograd_3x3, int winograd_4x4s2) {
     g_wgrad_f23 = winograd_3x3 < 0 ? -1 : (winograd_3x3 != 0);
