@@ -678,6 +678,16 @@ def test_frame_flags():
     x[1, 4, :, 5, 5] = 0     # a few zeros inside a real frame do not make it padding
     v = E.frame_flags(x.cuda(), 0.0).cpu().view(2, 5)
     assert v.tolist() == [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]]
+    # several chunks per frame (10 x 128 x 128: ten blocks each); real frames that look padded at the head of EVERY chunk -- the
+    # kernel leaves a chunk after its first 256 values only when one of them differs from the pad value
+    y = torch.zeros(1, 6, 10, 128, 128)
+    y[0, 0] = torch.randn(10, 128, 128)
+    y[0, 1, 9, 127, 127] = 1.0                     # only the very last value
+    y[0, 2, 0, 2, 0] = -3.0                        # value 256 of the first chunk
+    y[0, 3] = 7.0                                  # a constant frame that is not the pad value
+    y[0, 4, 5, 64, 1] = 1e-30                      # a tiny value in the middle
+    for pad, want in ((0.0, [1, 1, 1, 1, 1, 0]), (7.0, [1, 1, 1, 0, 1, 1])):
+        assert E.frame_flags(y.cuda(), pad).cpu().view(-1).tolist() == want, pad
 
 
 @pytest.mark.parametrize("training", [False, True])
