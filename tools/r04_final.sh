@@ -36,6 +36,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/lt_fetch -- 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/lt_write -- python tools/ltae_bench.py --no-attn --reps 2 > $O/lt_w.log 2>&1
 python tools/step_traffic.py $O/lt_fetch $O/lt_write $O/ltae_traffic.csv 2 > $O/lt_parse.log 2>&1 || tail -3 $O/lt_parse.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lt_stats -- python tools/ltae_bench.py --no-attn --reps 3 > $O/ltae_bench.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/mfma -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/mfma.json 2> $O/mfma.err
+python tools/mfma_util.py $O/mfma $O/mfma_util.csv > /dev/null
 timeout -k 10 300 python tools/tile_bench.py > $O/tile_bench.txt 2>&1 || tail -5 $O/tile_bench.txt
 find $O -name '*kernel_trace.csv' -delete
 find $O -name '*counter_collection.csv' -size +30M -delete
