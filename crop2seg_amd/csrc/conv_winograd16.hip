@@ -213,7 +213,9 @@ __global__ __launch_bounds__(512, 1) void conv_winograd16_kernel(Wino16Params p)
     // Requests (uniform across the workgroup).  The raw tile comes from HBM and is requested THREE chunks ahead of the MFMAs
     // (tools/wino16_diag.py: with two, ~130 us of the 64->64 @128^2 launch were waits for it), U (L2 hits) two ahead.  The U
     // chunk to request next is the one the raw side requested a step earlier: (u_ok, u_k).
-    const bool diag_stage = (C2S_W16_DIAG != 2 && (C2S_W16_DIAG < 5 || (C2S_W16_DIAG >= 13 && C2S_W16_DIAG <= 17)));
+    // 2, 5-7, 11, 12: nothing is staged after the first two chunks; 8 / 9 stop ONE stream (round 4: they had fallen under the
+    // same switch since round 3 and measured 'no staging' three times over -- likewise 10)
+    const bool diag_stage = C2S_W16_DIAG != 2 && (C2S_W16_DIAG < 5 || (C2S_W16_DIAG >= 8 && C2S_W16_DIAG <= 10) || C2S_W16_DIAG >= 100);
     bool u_ok = false, young_raw = false;
     int u_k = 0;
     auto stage_next_u = [&](int h0) {
