@@ -1,3 +1,5 @@
+# PMC stall counters of the 8-wave Winograd kernel's diagnostic builds (as built / no raw stream / no U stream / raw tiles from the L2):
+# python tools/wino16_diag.py --build 0 8 9 10 first.  ~50 s per pass: 20 passes.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/w16pmc; rm -rf $O; mkdir -p $O
@@ -10,6 +12,7 @@ for grp in "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES
   i=$((i+1))
   for v in 0 8 9 10; do
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/g${i}_v$v -- python tools/wino16_diag.py --child tools/_diag/libc2s_w16diag$v.so > $O/g${i}_v$v.log 2>&1 || echo "pass g$i v$v failed: $(tail -2 $O/g${i}_v$v.log)"
+    echo "pass g$i variant $v done"          # (a run that prints nothing for 7 minutes is taken to be hung)
   done
 done
 python - <<'PY'
