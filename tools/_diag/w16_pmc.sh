@@ -1,13 +1,12 @@
 # PMC stall counters of the 8-wave Winograd kernel's diagnostic builds (as built / no raw stream / no U stream / raw tiles from the L2):
-# python tools/wino16_diag.py --build 0 8 9 10 first.  ~50 s per pass: 20 passes.
+# python tools/wino16_diag.py --build 0 8 9 10 first.  ~50 s per pass.  (A pass with the TA_* / TD_* stall counters hung rocprofv3
+# twice on this pool -- the run was killed after seven silent minutes -- and is not in the list.)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/w16pmc; rm -rf $O; mkdir -p $O
 i=0
 for grp in "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-           "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum TD_TC_STALL_sum" \
-           "TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_RDRET_STALL_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   for v in 0 8 9 10; do
